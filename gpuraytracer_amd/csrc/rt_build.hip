@@ -1,0 +1,607 @@
+// Per-frame LBVH build for gfx950: Morton codes, stable LSD radix sort, leaf and level emission.
+//
+// Results are bit-identical to the reference's compute shaders
+//   shader/CS_GenerateMortonCodes.hlsl, CS_SortCount.hlsl, CS_SortPrefixSum.hlsl, CS_SortSort.hlsl,
+//   CS_BVHBuildLeaves.hlsl, CS_BVHBuild.hlsl
+// as sequenced by src/RaytracerPipeline.cpp:276-383 and 475-562, but the work decomposition is
+// new: the reference scatters with ONE workgroup whose 256 threads each scan all N keys; here
+// every pass is tile-parallel (per-tile digit counts -> per-digit scan over tiles -> ranked scatter
+// with wave64 ballots and an LDS-staged reorder), and the ~log2(N) per-level dispatches are fused
+// eight levels at a time through LDS.
+//
+// Built with -ffp-contract=off: the Morton quantisation must round once per written operation.
+
+#include "rt_internal.h"
+
+namespace {
+
+constexpr int kThreads = RT_SORT_THREADS;
+constexpr int kItems = RT_SORT_ITEMS;
+constexpr int kTile = RT_SORT_TILE;
+
+__device__ __forceinline__ uint32_t left_shift3(uint32_t v) {
+    // shader/CS_GenerateMortonCodes.hlsl:30-38 -- the "|=" (rather than "= (v | v << s) & m") is the
+    // reference's own and is kept: it leaves stray low bits in place.
+    v |= (v << 16) & 0x030000ffu;
+    v |= (v << 8) & 0x0300f00fu;
+    v |= (v << 4) & 0x030c30c3u;
+    v |= (v << 2) & 0x09249249u;
+    return v;
+}
+
+__device__ __forceinline__ float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+__device__ __forceinline__ uint32_t morton_code(float p1x, float p1y, float p1z, float p2x, float p2y, float p2z,
+                                                 float p3x, float p3y, float p3z, const float* smin, const float* smax) {
+    // shader/CS_GenerateMortonCodes.hlsl:58-66
+    float cx = 0.333333f * ((p1x + p2x) + p3x);
+    float cy = 0.333333f * ((p1y + p2y) + p3y);
+    float cz = 0.333333f * ((p1z + p2z) + p3z);
+    float qx = saturatef((cx - smin[0]) / (smax[0] - smin[0])) * 1023.0f;
+    float qy = saturatef((cy - smin[1]) / (smax[1] - smin[1])) * 1023.0f;
+    float qz = saturatef((cz - smin[2]) / (smax[2] - smin[2])) * 1023.0f;
+    return (left_shift3((uint32_t)qz) << 2) | (left_shift3((uint32_t)qy) << 1) | left_shift3((uint32_t)qx);
+}
+
+struct SceneBounds { float mn[3]; float mx[3]; };
+
+// reference layout: Indices -> Vertices (48-byte stride) -> uint4(code, 3*tri, 0, 0)
+__global__ __launch_bounds__(256) void k_morton_ref(SceneBounds sb, uint32_t n, const uint32_t* __restrict__ indices,
+                                                    const rt_vertex* __restrict__ verts, uint4* __restrict__ morton,
+                                                    uint4* __restrict__ freq) {
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < n) {
+        uint32_t ci = t * 3u;
+        const float* a = verts[indices[ci]].position;
+        const float* b = verts[indices[ci + 1]].position;
+        const float* c = verts[indices[ci + 2]].position;
+        uint32_t code = morton_code(a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2], sb.mn, sb.mx);
+        morton[t] = make_uint4(code, ci, 0u, 0u);
+    }
+    if (t < 256u) freq[t].x = 0u;
+}
+
+// gathers positions into 3 x float4 per triangle (original order) for 128-bit loads
+__global__ __launch_bounds__(256) void k_pack(uint32_t n, const uint32_t* __restrict__ indices,
+                                              const rt_vertex* __restrict__ verts, float4* __restrict__ tris) {
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    uint32_t ci = t * 3u;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float* p = verts[indices[ci + k]].position;
+        tris[ci + k] = make_float4(p[0], p[1], p[2], 0.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_morton_packed(SceneBounds sb, uint32_t n, const float4* __restrict__ tris,
+                                                       uint2* __restrict__ keys) {
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    uint32_t ci = t * 3u;
+    float4 a = tris[ci], b = tris[ci + 1], c = tris[ci + 2];
+    uint32_t code = morton_code(a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, sb.mn, sb.mx);
+    keys[t] = make_uint2(code, ci);
+}
+
+__global__ __launch_bounds__(256) void k_expand_keys(uint32_t n, const uint2* __restrict__ keys, uint4* __restrict__ morton) {
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < n) { uint2 k = keys[t]; morton[t] = make_uint4(k.x, k.y, 0u, 0u); }
+}
+
+// ------------------------------------------------------------------ radix sort ----
+
+// wave64 inclusive scan by lane shuffles
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread workgroup; *total receives the sum.
+// tmp: 4 words of LDS. Contains two barriers.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, uint32_t* total) {
+    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan(v, lane);
+    __syncthreads();                       // tmp may still be read from a previous call
+    if (lane == 63u) tmp[wave] = incl;
+    __syncthreads();
+    uint32_t w0 = tmp[0], w1 = tmp[1], w2 = tmp[2], w3 = tmp[3];
+    uint32_t before = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+    *total = w0 + w1 + w2 + w3;
+    return before + incl - v;
+}
+
+// Per-tile digit counts. STRIDE = 32-bit words per element (4: reference uint4 records, 2: packed
+// pairs). REF additionally performs the reference count shader's side effects: copy .xy to the
+// temp buffer and add the counts to the global counters' .x.
+template <int STRIDE, bool REF>
+__global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ in, uint32_t* __restrict__ temp, uint32_t n,
+                                                   uint32_t shift, uint32_t* __restrict__ table, uint32_t tiles,
+                                                   uint4* __restrict__ freq) {
+    __shared__ uint32_t hist[4][256];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    hist[0][tid] = 0u; hist[1][tid] = 0u; hist[2][tid] = 0u; hist[3][tid] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (uint32_t)kTile;
+#pragma unroll
+    for (int j = 0; j < kItems; j++) {
+        uint32_t i = base + (uint32_t)j * 256u + tid;
+        if (i < n) {
+            uint2 kv = *reinterpret_cast<const uint2*>(in + (size_t)i * STRIDE);
+            if (REF) *reinterpret_cast<uint2*>(temp + (size_t)i * STRIDE) = kv;
+            atomicAdd(&hist[wave][(kv.x >> shift) & 0xffu], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t c = hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid];
+    table[(size_t)tid * tiles + blockIdx.x] = c;
+    if (REF && c) atomicAdd(&freq[tid].x, c);
+}
+
+// One workgroup per digit: exclusive scan of that digit's counts over the tiles, in place.
+__global__ __launch_bounds__(256) void k_sort_scan(uint32_t* __restrict__ table, uint32_t tiles, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t tmp[4];
+    uint32_t* row = table + (size_t)blockIdx.x * tiles;
+    const uint32_t tid = threadIdx.x;
+    uint32_t carry = 0u;
+    for (uint32_t base = 0; base < tiles; base += 1024u) {
+        // four consecutive entries per thread
+        uint32_t i0 = base + tid * 4u;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i0 + k < tiles) ? row[i0 + k] : 0u;
+        uint32_t sum = v[0] + v[1] + v[2] + v[3], total;
+        uint32_t ex = block_excl_scan(sum, tmp, &total) + carry;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < tiles) row[i0 + k] = ex;
+            ex += v[k];
+        }
+        carry += total;
+    }
+    if (tid == 0) totals[blockIdx.x] = carry;
+}
+
+// shader/CS_SortPrefixSum.hlsl: .y = exclusive prefix sum of .x over the 256 counters
+__global__ __launch_bounds__(256) void k_freq_scan(uint4* __restrict__ freq) {
+    __shared__ uint32_t tmp[4];
+    uint32_t total;
+    uint32_t ex = block_excl_scan(freq[threadIdx.x].x, tmp, &total);
+    freq[threadIdx.x].y = ex;
+}
+
+// Stable scatter of one tile. Keys are held wave-striped (wave w owns elements
+// [w*64*kItems, (w+1)*64*kItems) of the tile; item j of lane l is element j*64 + l), so the order
+// (wave, item, lane) is the input order. Rank inside the wave comes from a ballot match on the 8
+// digit bits; per-wave running digit counts live in LDS. Keys are then reordered through LDS so
+// that the global writes are runs of consecutive addresses per digit.
+template <int STRIDE_IN, int STRIDE_OUT, bool REF>
+__global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n,
+                                                      uint32_t shift, const uint32_t* __restrict__ table, uint32_t tiles,
+                                                      const uint32_t* __restrict__ totals, uint4* __restrict__ freq) {
+    __shared__ uint32_t s_keys[kTile];
+    __shared__ uint32_t s_vals[kTile];
+    __shared__ uint32_t wave_hist[4][256];
+    __shared__ uint32_t digit_start[256];
+    __shared__ uint32_t gbase[256];
+    __shared__ uint32_t tmp[4];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tile_base = tile * (uint32_t)kTile;
+    const uint32_t tile_count = min((uint32_t)kTile, n - tile_base);
+
+    wave_hist[0][tid] = 0u; wave_hist[1][tid] = 0u; wave_hist[2][tid] = 0u; wave_hist[3][tid] = 0u;
+
+    uint32_t key[kItems], val[kItems], rank[kItems];
+    const uint32_t wbase = wave * 64u * (uint32_t)kItems;
+#pragma unroll
+    for (int j = 0; j < kItems; j++) {
+        uint32_t e = wbase + (uint32_t)j * 64u + lane;
+        key[j] = 0u; val[j] = 0u;
+        if (e < tile_count) {
+            uint2 kv = *reinterpret_cast<const uint2*>(in + (size_t)(tile_base + e) * STRIDE_IN);
+            key[j] = kv.x; val[j] = kv.y;
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < kItems; j++) {
+        const uint32_t e = wbase + (uint32_t)j * 64u + lane;
+        const bool valid = e < tile_count;
+        const uint32_t d = (key[j] >> shift) & 0xffu;
+        unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            unsigned long long bb = __builtin_amdgcn_ballot_w64(valid && bit);
+            peers &= bit ? bb : ~bb;
+        }
+        const uint32_t lower = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        const uint32_t cnt = (uint32_t)__popcll(peers);
+        uint32_t pre = 0u;
+        if (valid) pre = wave_hist[wave][d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && lower == 0u) wave_hist[wave][d] = pre + cnt;
+        __builtin_amdgcn_wave_barrier();
+        rank[j] = pre + lower;
+    }
+    __syncthreads();
+
+    {   // thread = digit: digit starts inside the tile, per-wave offsets, global bases
+        uint32_t c0 = wave_hist[0][tid], c1 = wave_hist[1][tid], c2 = wave_hist[2][tid], c3 = wave_hist[3][tid];
+        uint32_t total;
+        uint32_t start = block_excl_scan(c0 + c1 + c2 + c3, tmp, &total);
+        uint32_t dbase;
+        if (REF) {
+            dbase = freq[tid].y;
+        } else {
+            uint32_t t2;
+            dbase = block_excl_scan(totals[tid], tmp, &t2);
+        }
+        digit_start[tid] = start;
+        gbase[tid] = dbase + table[(size_t)tid * tiles + tile];
+        wave_hist[0][tid] = start;
+        wave_hist[1][tid] = start + c0;
+        wave_hist[2][tid] = start + c0 + c1;
+        wave_hist[3][tid] = start + c0 + c1 + c2;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < kItems; j++) {
+        const uint32_t e = wbase + (uint32_t)j * 64u + lane;
+        if (e < tile_count) {
+            uint32_t p = wave_hist[wave][(key[j] >> shift) & 0xffu] + rank[j];
+            s_keys[p] = key[j];
+            s_vals[p] = val[j];
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < kItems; j++) {
+        uint32_t p = (uint32_t)j * 256u + tid;
+        if (p < tile_count) {
+            uint32_t k = s_keys[p];
+            uint32_t d = (k >> shift) & 0xffu;
+            uint32_t g = gbase[d] + (p - digit_start[d]);
+            *reinterpret_cast<uint2*>(out + (size_t)g * STRIDE_OUT) = make_uint2(k, s_vals[p]);
+        }
+    }
+    if (REF && tile == 0u) freq[tid].x = 0u;      // shader/CS_SortSort.hlsl:34
+}
+
+// ------------------------------------------------------------------- hierarchy ----
+
+struct Box { float mn[3]; float mx[3]; };
+
+__device__ __forceinline__ void store_node(rt_aabb* nodes, uint32_t idx, const Box& b, uint32_t l0, uint32_t l1) {
+    float4* p = reinterpret_cast<float4*>(nodes + idx);
+    p[0] = make_float4(b.mn[0], b.mn[1], b.mn[2], b.mx[0]);
+    p[1] = make_float4(b.mx[1], b.mx[2], __uint_as_float(l0), __uint_as_float(l1));
+}
+
+// Builds up to eight levels above level k0 from the (up to) 256 level-k0 boxes the workgroup holds in
+// LDS slot order (slot s <-> node blockIdx.x*256 + s of level k0). Same arithmetic as
+// shader/CS_BVHBuild.hlsl:28-47: min/max union, links (first child, second child or 0xffffffff).
+__device__ __forceinline__ void upsweep_block(Box mine, uint32_t k0, const rt_levels& lv, rt_aabb* __restrict__ nodes,
+                                              float (*s_box)[6]) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t cnt = 256u;
+    uint32_t k = k0;
+#pragma unroll 1
+    for (int step = 0; step < 8; step++) {
+        if (k + 1u >= lv.count) break;
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 3; a++) { s_box[tid][a] = mine.mn[a]; s_box[tid][3 + a] = mine.mx[a]; }
+        __syncthreads();
+        k++;
+        cnt >>= 1;
+        const uint32_t gi = blockIdx.x * cnt + tid;
+        if (tid < cnt && gi < lv.n[k]) {
+            const uint32_t c0 = 2u * gi;
+            const bool has2 = (c0 + 1u) < lv.n[k - 1];
+            const uint32_t s0 = 2u * tid, s1 = has2 ? s0 + 1u : s0;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                mine.mn[a] = fminf(s_box[s0][a], s_box[s1][a]);
+                mine.mx[a] = fmaxf(s_box[s0][3 + a], s_box[s1][3 + a]);
+            }
+            const uint32_t l0 = lv.off[k - 1] + c0;
+            store_node(nodes, lv.off[k] + gi, mine, l0, has2 ? l0 + 1u : 0xffffffffu);
+        }
+    }
+}
+
+// Leaves (shader/CS_BVHBuildLeaves.hlsl:28-63). PACKED reads the packed pair array and the packed
+// triangles and also emits the Morton-ordered triangle copy; otherwise the reference layout
+// (uint4 records, Indices -> Vertices). FUSED continues with up to eight levels in the same launch.
+template <bool PACKED, bool FUSED>
+__global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv, const uint32_t* __restrict__ sorted,
+                                                const uint32_t* __restrict__ indices, const rt_vertex* __restrict__ verts,
+                                                const float4* __restrict__ tris, float4* __restrict__ sorted_tris,
+                                                rt_aabb* __restrict__ nodes) {
+    __shared__ float s_box[256][6];
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t leaves = (num_prims + 1u) / 2u;
+    Box b;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { b.mn[a] = 1e30f; b.mx[a] = -1e30f; }
+    if (g < leaves) {
+        constexpr int STRIDE = PACKED ? 2 : 4;
+        uint32_t ci0 = sorted[(size_t)(2u * g) * STRIDE + 1];
+        uint32_t ci1 = 0xffffffffu;
+        const bool two = (2u * g + 1u) < num_prims;
+        if (two) ci1 = sorted[(size_t)(2u * g + 1u) * STRIDE + 1];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            if (i >= 3 && !two) break;
+            const uint32_t ci = (i < 3) ? ci0 : ci1;
+            float px, py, pz;
+            if (PACKED) {
+                float4 p = tris[ci + (uint32_t)(i % 3)];
+                px = p.x; py = p.y; pz = p.z;
+                if (i % 3 == 0) p.w = __uint_as_float(ci);
+                sorted_tris[(size_t)(2u * g) * 3u + (uint32_t)i] = p;
+            } else {
+                const float* p = verts[indices[ci + (uint32_t)(i % 3)]].position;
+                px = p[0]; py = p[1]; pz = p[2];
+            }
+            b.mn[0] = fminf(b.mn[0], px); b.mn[1] = fminf(b.mn[1], py); b.mn[2] = fminf(b.mn[2], pz);
+            b.mx[0] = fmaxf(b.mx[0], px); b.mx[1] = fmaxf(b.mx[1], py); b.mx[2] = fmaxf(b.mx[2], pz);
+        }
+        store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
+    }
+    if (FUSED) upsweep_block(b, 0u, lv, nodes, s_box);
+}
+
+// continues the up-sweep from level k0 (already in memory), eight levels per launch
+__global__ __launch_bounds__(256) void k_upsweep(uint32_t k0, rt_levels lv, rt_aabb* __restrict__ nodes) {
+    __shared__ float s_box[256][6];
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    Box b;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { b.mn[a] = 1e30f; b.mx[a] = -1e30f; }
+    if (g < lv.n[k0]) {
+        const float4* p = reinterpret_cast<const float4*>(nodes + lv.off[k0] + g);
+        float4 lo = p[0], hi = p[1];
+        b.mn[0] = lo.x; b.mn[1] = lo.y; b.mn[2] = lo.z; b.mx[0] = lo.w; b.mx[1] = hi.x; b.mx[2] = hi.y;
+    }
+    upsweep_block(b, k0, lv, nodes, s_box);
+}
+
+// one level, reference parameters (shader/CS_BVHBuild.hlsl:25-48)
+__global__ __launch_bounds__(256) void k_level(rt_bvh_info info, rt_aabb* __restrict__ nodes) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= (info.num_children + 1u) / 2u) return;
+    uint32_t i1 = 2u * t + info.previous_index, i2 = i1 + 1u;
+    const float4* p = reinterpret_cast<const float4*>(nodes + i1);
+    float4 a0 = p[0], a1 = p[1], b0 = a0, b1 = a1;
+    if ((i2 - info.previous_index) < info.num_children) { b0 = p[2]; b1 = p[3]; }
+    else i2 = 0xffffffffu;
+    Box r;
+    r.mn[0] = fminf(a0.x, b0.x); r.mn[1] = fminf(a0.y, b0.y); r.mn[2] = fminf(a0.z, b0.z);
+    r.mx[0] = fmaxf(a0.w, b0.w); r.mx[1] = fmaxf(a1.x, b1.x); r.mx[2] = fmaxf(a1.y, b1.y);
+    store_node(nodes, info.current_index + t, r, i1, i2);
+}
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
+
+inline SceneBounds make_bounds(const float* mn, const float* mx) {
+    SceneBounds sb;
+    for (int k = 0; k < 3; k++) { sb.mn[k] = mn[k]; sb.mx[k] = mx[k]; }
+    return sb;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rt_bvh_node_count(uint32_t num_primitives) {
+    rt_levels lv;
+    if (!rt_make_levels(num_primitives, &lv)) return 0u;
+    uint32_t total = 0u;
+    for (uint32_t k = 0; k < lv.count; k++) total += lv.n[k];
+    return total;
+}
+
+int rt_generate_morton_codes(rt_device* dev, const rt_morton_code_info* info, const rt_buffer* indices,
+                             const rt_buffer* vertices, rt_buffer* morton_codes, rt_buffer* code_frequencies) {
+    if (!dev || !info || !indices || !vertices || !morton_codes || !code_frequencies) return RT_ERR_INVALID_ARGUMENT;
+    const uint32_t n = info->num_primitives;
+    if (indices->bytes < (size_t)n * 12u || morton_codes->bytes < (size_t)n * 16u || code_frequencies->bytes < 256u * 16u)
+        return RT_ERR_BUFFER_TOO_SMALL;
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+    // the shader's "thread < 256" counter reset needs at least one workgroup
+    const uint32_t groups = n ? div_up(n, 256u) : 1u;
+    hipLaunchKernelGGL(k_morton_ref, dim3(groups), dim3(256), 0, dev->stream, make_bounds(info->scene_min, info->scene_max), n,
+                       (const uint32_t*)indices->ptr, (const rt_vertex*)vertices->ptr, (uint4*)morton_codes->ptr,
+                       (uint4*)code_frequencies->ptr);
+    return rt_launch_status();
+}
+
+int rt_sort_count(rt_device* dev, const rt_sort_info* info, const rt_buffer* morton_codes, rt_buffer* temp_morton_codes,
+                  rt_buffer* code_frequencies) {
+    if (!dev || !info || !morton_codes || !temp_morton_codes || !code_frequencies) return RT_ERR_INVALID_ARGUMENT;
+    const uint32_t n = info->num_elements;
+    if (info->sort_pass_index > 3u) return RT_ERR_INVALID_ARGUMENT;
+    if (morton_codes->bytes < (size_t)n * 16u || temp_morton_codes->bytes < (size_t)n * 16u || code_frequencies->bytes < 4096u)
+        return RT_ERR_BUFFER_TOO_SMALL;
+    if (!n) return RT_OK;
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+    rc = rt_sort_workspace(dev, n);
+    if (rc) return rc;
+    const uint32_t tiles = div_up(n, kTile);
+    hipLaunchKernelGGL((k_sort_hist<4, true>), dim3(tiles), dim3(256), 0, dev->stream, (const uint32_t*)morton_codes->ptr,
+                       (uint32_t*)temp_morton_codes->ptr, n, 8u * info->sort_pass_index, dev->sort_table, tiles,
+                       (uint4*)code_frequencies->ptr);
+    return rt_launch_status();
+}
+
+int rt_sort_prefix_sum(rt_device* dev, const rt_sort_info* info, rt_buffer* code_frequencies) {
+    if (!dev || !info || !code_frequencies) return RT_ERR_INVALID_ARGUMENT;
+    if (code_frequencies->bytes < 4096u) return RT_ERR_BUFFER_TOO_SMALL;
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_freq_scan, dim3(1), dim3(256), 0, dev->stream, (uint4*)code_frequencies->ptr);
+    rc = rt_launch_status();
+    if (rc) return rc;
+    const uint32_t n = info->num_elements;
+    if (!n) return RT_OK;
+    rc = rt_sort_workspace(dev, n);
+    if (rc) return rc;
+    const uint32_t tiles = div_up(n, kTile);
+    hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, dev->stream, dev->sort_table, tiles, dev->sort_totals);
+    return rt_launch_status();
+}
+
+int rt_sort_sort(rt_device* dev, const rt_sort_info* info, rt_buffer* morton_codes, const rt_buffer* temp_morton_codes,
+                 rt_buffer* code_frequencies) {
+    if (!dev || !info || !morton_codes || !temp_morton_codes || !code_frequencies) return RT_ERR_INVALID_ARGUMENT;
+    const uint32_t n = info->num_elements;
+    if (info->sort_pass_index > 3u) return RT_ERR_INVALID_ARGUMENT;
+    if (morton_codes->bytes < (size_t)n * 16u || temp_morton_codes->bytes < (size_t)n * 16u || code_frequencies->bytes < 4096u)
+        return RT_ERR_BUFFER_TOO_SMALL;
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+    const uint32_t tiles = div_up(n, kTile);
+    if (!n || (size_t)tiles * 256u > dev->sort_table_words) {
+        if (n) return RT_ERR_INVALID_ARGUMENT;    // scatter without the count step of this pass
+        return RT_OK;
+    }
+    hipLaunchKernelGGL((k_sort_scatter<4, 4, true>), dim3(tiles), dim3(256), 0, dev->stream,
+                       (const uint32_t*)temp_morton_codes->ptr, (uint32_t*)morton_codes->ptr, n, 8u * info->sort_pass_index,
+                       dev->sort_table, tiles, dev->sort_totals, (uint4*)code_frequencies->ptr);
+    return rt_launch_status();
+}
+
+int rt_bvh_build_leaves(rt_device* dev, const rt_bvh_info* info, const rt_buffer* indices, const rt_buffer* vertices,
+                        const rt_buffer* morton_codes, rt_buffer* bvh) {
+    if (!dev || !info || !indices || !vertices || !morton_codes || !bvh) return RT_ERR_INVALID_ARGUMENT;
+    const uint32_t n = info->num_children;
+    const uint32_t leaves = (n + 1u) / 2u;
+    if (morton_codes->bytes < (size_t)n * 16u || bvh->bytes < ((size_t)leaves + 1u) * 32u) return RT_ERR_BUFFER_TOO_SMALL;
+    if (!n) return RT_OK;
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+    rt_levels lv;
+    lv.count = 0;
+    hipLaunchKernelGGL((k_leaves<false, false>), dim3(div_up(leaves, 256u)), dim3(256), 0, dev->stream, n, lv,
+                       (const uint32_t*)morton_codes->ptr, (const uint32_t*)indices->ptr, (const rt_vertex*)vertices->ptr,
+                       (const float4*)nullptr, (float4*)nullptr, (rt_aabb*)bvh->ptr);
+    return rt_launch_status();
+}
+
+int rt_bvh_build(rt_device* dev, const rt_bvh_info* info, rt_buffer* bvh) {
+    if (!dev || !info || !bvh) return RT_ERR_INVALID_ARGUMENT;
+    const uint32_t parents = (info->num_children + 1u) / 2u;
+    if (!parents) return RT_OK;
+    const size_t last_read = (size_t)info->previous_index + info->num_children;      // one past the last child
+    const size_t last_write = (size_t)info->current_index + parents;
+    if (bvh->bytes < last_read * 32u || bvh->bytes < last_write * 32u) return RT_ERR_BUFFER_TOO_SMALL;
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_level, dim3(div_up(parents, 256u)), dim3(256), 0, dev->stream, *info, (rt_aabb*)bvh->ptr);
+    return rt_launch_status();
+}
+
+int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
+    if (!out) return RT_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!dev || max_primitives < 3u || max_primitives > 0x2aaaaaaau) return RT_ERR_INVALID_ARGUMENT;
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+    rc = rt_sort_workspace(dev, max_primitives);
+    if (rc) return rc;
+    rt_accel* a = new (std::nothrow) rt_accel();
+    if (!a) return RT_ERR_OUT_OF_MEMORY;
+    a->dev = dev;
+    a->max_prims = max_primitives;
+    a->num_prims = 0;
+    a->tris = a->sorted_tris = nullptr;
+    a->keys_a = a->keys_b = nullptr;
+    const size_t tri_bytes = (size_t)max_primitives * 48u, key_bytes = (size_t)max_primitives * 8u;
+    hipError_t e = hipMalloc((void**)&a->tris, tri_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&a->sorted_tris, tri_bytes + 48u);   // odd counts pad the last leaf
+    if (e == hipSuccess) e = hipMalloc((void**)&a->keys_a, key_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&a->keys_b, key_bytes);
+    if (e != hipSuccess) {
+        rt_accel_destroy(a);
+        return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
+    }
+    *out = a;
+    return RT_OK;
+}
+
+int rt_accel_destroy(rt_accel* a) {
+    if (!a) return RT_ERR_INVALID_ARGUMENT;
+    (void)rt_set_device(a->dev);
+    (void)hipStreamSynchronize(a->dev->stream);
+    if (a->tris) (void)hipFree(a->tris);
+    if (a->sorted_tris) (void)hipFree(a->sorted_tris);
+    if (a->keys_a) (void)hipFree(a->keys_a);
+    if (a->keys_b) (void)hipFree(a->keys_b);
+    delete a;
+    return RT_OK;
+}
+
+int rt_accel_pack(rt_accel* a, uint32_t num_primitives, const rt_buffer* indices, const rt_buffer* vertices) {
+    if (!a || !indices || !vertices) return RT_ERR_INVALID_ARGUMENT;
+    if (num_primitives < 3u) return RT_ERR_TOO_FEW_PRIMITIVES;
+    if (num_primitives > a->max_prims) return RT_ERR_INVALID_ARGUMENT;
+    if (indices->bytes < (size_t)num_primitives * 12u) return RT_ERR_BUFFER_TOO_SMALL;
+    int rc = rt_set_device(a->dev);
+    if (rc) return rc;
+    a->num_prims = num_primitives;
+    hipLaunchKernelGGL(k_pack, dim3(div_up(num_primitives, 256u)), dim3(256), 0, a->dev->stream, num_primitives,
+                       (const uint32_t*)indices->ptr, (const rt_vertex*)vertices->ptr, a->tris);
+    return rt_launch_status();
+}
+
+int rt_accel_build(rt_accel* a, const float scene_min[3], const float scene_max[3], rt_buffer* bvh, rt_buffer* morton_codes) {
+    if (!a || !scene_min || !scene_max || !bvh) return RT_ERR_INVALID_ARGUMENT;
+    const uint32_t n = a->num_prims;
+    rt_levels lv;
+    if (!rt_make_levels(n, &lv)) return RT_ERR_TOO_FEW_PRIMITIVES;
+    if (bvh->bytes < (size_t)rt_bvh_node_count(n) * 32u) return RT_ERR_BUFFER_TOO_SMALL;
+    if (morton_codes && morton_codes->bytes < (size_t)n * 16u) return RT_ERR_BUFFER_TOO_SMALL;
+    rt_device* dev = a->dev;
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+    hipStream_t s = dev->stream;
+
+    hipLaunchKernelGGL(k_morton_packed, dim3(div_up(n, 256u)), dim3(256), 0, s, make_bounds(scene_min, scene_max), n, a->tris,
+                       a->keys_a);
+    const uint32_t tiles = div_up(n, kTile);
+    uint2* src = a->keys_a;
+    uint2* dst = a->keys_b;
+    for (uint32_t pass = 0; pass < 4u; pass++) {
+        const uint32_t shift = 8u * pass;
+        hipLaunchKernelGGL((k_sort_hist<2, false>), dim3(tiles), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)nullptr, n,
+                           shift, dev->sort_table, tiles, (uint4*)nullptr);
+        hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, s, dev->sort_table, tiles, dev->sort_totals);
+        hipLaunchKernelGGL((k_sort_scatter<2, 2, false>), dim3(tiles), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, n,
+                           shift, dev->sort_table, tiles, dev->sort_totals, (uint4*)nullptr);
+        uint2* t = src; src = dst; dst = t;
+    }
+    // four passes: the sorted pairs are back in keys_a (= src)
+    const uint32_t leaves = lv.n[0];
+    hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)src,
+                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr);
+    for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
+        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr);
+    if (morton_codes)
+        hipLaunchKernelGGL(k_expand_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, n, src, (uint4*)morton_codes->ptr);
+    return rt_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// Internal definitions shared by the gpurt translation units (not part of the C-ABI).
+#ifndef GPURT_INTERNAL_H
+#define GPURT_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gpurt.h"
+
+struct rt_device {
+    int gpu;
+    hipStream_t stream;
+    bool owns_stream;
+    // workspace of the radix sort's count/scan/scatter triple (per-tile digit counts)
+    uint32_t* sort_table;      // [256][tiles], digit-major
+    size_t sort_table_words;
+    uint32_t* sort_totals;     // [256] digit totals + [256] exclusive digit bases
+};
+
+struct rt_buffer {
+    rt_device* dev;
+    void* ptr;
+    size_t bytes;
+    bool owned;
+};
+
+struct rt_event {
+    rt_device* dev;
+    hipEvent_t ev;
+};
+
+struct rt_accel {
+    rt_device* dev;
+    uint32_t max_prims;
+    uint32_t num_prims;        // set by rt_accel_pack
+    float4* tris;              // [3*max_prims] packed positions, original order
+    float4* sorted_tris;       // [3*max_prims] packed positions, Morton order (w of vertex 0 = 3*tri)
+    uint2* keys_a;             // [max_prims] (code, 3*tri)
+    uint2* keys_b;             // [max_prims]
+};
+
+#define RT_HIP(call)                                              \
+    do {                                                          \
+        hipError_t e_ = (call);                                   \
+        if (e_ != hipSuccess) return RT_ERR_HIP_BASE + (int)e_;   \
+    } while (0)
+
+static inline int rt_set_device(const rt_device* dev) {
+    if (!dev) return RT_ERR_INVALID_ARGUMENT;
+    RT_HIP(hipSetDevice(dev->gpu));
+    return RT_OK;
+}
+
+static inline int rt_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? RT_OK : RT_ERR_HIP_BASE + (int)e;
+}
+
+// radix sort tiling: 256 threads x RT_SORT_ITEMS keys per workgroup
+#define RT_SORT_THREADS 256
+#define RT_SORT_ITEMS 8
+#define RT_SORT_TILE (RT_SORT_THREADS * RT_SORT_ITEMS)
+
+int rt_sort_workspace(rt_device* dev, uint32_t num_elements);   // grows dev->sort_table as needed
+
+// level schedule of the balanced hierarchy (src/RaytracerPipeline.cpp:465-467, 497-559):
+// level 0 = leaves at node 1; level k has ceil(n_{k-1} / 2) nodes appended after level k-1;
+// the level holding a single node is the root and is stored at node 0.
+struct rt_levels {
+    uint32_t count;            // number of levels including the root level
+    uint32_t n[33];            // nodes per level
+    uint32_t off[33];          // first node index of each level (root level: 0)
+};
+static inline bool rt_make_levels(uint32_t num_prims, rt_levels* lv) {
+    if (num_prims < 3u) return false;
+    uint32_t n = (num_prims + 1u) / 2u, off = 1u, k = 0;
+    for (;;) {
+        lv->n[k] = n;
+        lv->off[k] = (n == 1u) ? 0u : off;
+        k++;
+        if (n == 1u) break;
+        off += n;
+        n = (n + 1u) / 2u;
+    }
+    lv->count = k;
+    return true;
+}
+
+#endif

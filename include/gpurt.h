@@ -1,0 +1,166 @@
+/* gpurt -- C-ABI of the MI355X (gfx950) LBVH-build + ray-trace path.
+ *
+ * This is the boundary a maintainer of the reference binds to in place of its
+ * Direct3D 12 layers: device + command submission (src/GPUDevice.h, src/GPUScheduler.h),
+ * compute pipeline states (src/PipelineState.h) and GPU resources
+ * (src/ShaderResources.h). One launcher per compute shader takes the shader's
+ * constant buffer as a POD struct (byte-identical to the reference's) and the
+ * buffers the shader binds, in register order. Launches are asynchronous on the
+ * device's stream; stream order replaces the reference's UAV barriers.
+ *
+ * Conventions: every function returns 0 on success or a non-zero error code
+ * (RT_ERR_* below, or 0x1000 + hipError_t for a failed HIP call); nothing throws
+ * or aborts. Handles are opaque. Host memory stays owned by the caller, device
+ * memory by the buffer handle. All calls for one device must come from one
+ * thread at a time (the reference drives its pipeline from one render thread,
+ * src/Main.cpp:18-25); that thread need not be the creator.
+ */
+#ifndef GPURT_H
+#define GPURT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID_ARGUMENT 1   /* null handle, size mismatch, count out of range */
+#define RT_ERR_TOO_FEW_PRIMITIVES 2 /* fewer than 3 triangles: the reference's level loop never ends */
+#define RT_ERR_BUFFER_TOO_SMALL 3
+#define RT_ERR_OUT_OF_MEMORY 4
+#define RT_ERR_HIP_BASE 0x1000      /* 0x1000 + hipError_t */
+
+typedef struct rt_device rt_device;
+typedef struct rt_buffer rt_buffer;
+typedef struct rt_event rt_event;
+typedef struct rt_accel rt_accel;
+
+/* ---- element layouts (shader/Raytracer.hlsli:15-40, src/RaytracerMesh.h:14-46,
+ *      shader/PerRayShading.hlsli:27-48, src/TextureAtlas.h:14-20) ---- */
+typedef struct { float position[3]; float uv[2]; float normal[3]; float tangent[3]; uint32_t material_id; } rt_vertex; /* 48 B */
+typedef struct { float origin[3]; float direction[3]; float t_min; float t_max; } rt_ray;                               /* 32 B */
+typedef struct { float min[3]; float max[3]; uint32_t link[2]; } rt_aabb;                                               /* 32 B */
+typedef struct {
+    float albedo[3]; float roughness; float f0_color[3]; float metallic; float emissive[3];
+    uint32_t albedo_texture, roughness_texture, f0_texture, metallic_texture, emissive_texture;
+} rt_pbr_material;                                                                                                       /* 64 B */
+typedef struct { uint32_t offset, width, height, row_pitch; } rt_texture_id;                                            /* 16 B */
+
+/* ---- constant buffers (src/RaytracerPipeline.h:36-45, 94-105, 148-154, 192-199, 241-246) ---- */
+typedef struct {
+    float inverse_view[16];        /* as XMStoreFloat4x4 leaves it: inverse(transpose(view)) row-major */
+    float inverse_projection[16];
+    int32_t screen_size[2];
+    float aa_sample_spread;
+    float dof_sample_spread;
+    uint32_t max_rays_per_pixel;
+    uint32_t rng_seed[3];
+} rt_camera_ray_gen_info;                                                                                                /* 160 B */
+typedef struct { float scene_min[4]; float scene_max[4]; uint32_t num_primitives; uint32_t padding[3]; } rt_morton_code_info; /* 48 B */
+typedef struct { uint32_t num_elements; uint32_t sort_pass_index; } rt_sort_info;                                       /* 8 B */
+typedef struct { uint32_t num_children, previous_index, current_index, padding; } rt_bvh_info;                          /* 16 B */
+typedef struct { int32_t screen_dimensions[2]; uint32_t num_indices, num_rays, max_rays_per_pixel; uint32_t rng_seed[3]; } rt_trace_rays_info; /* 32 B */
+typedef struct { int32_t screen_dimensions[2]; uint32_t max_rays_per_pixel; uint32_t num_samples; } rt_generate_final_image_info;             /* 16 B */
+
+/* ---- device, stream, events: replaces DX12Device (src/GPUDevice.h:17-38) and
+ *      GPUScheduler::Record/Execute/Flush (src/GPUScheduler.cpp:130-166) ---- */
+int rt_device_create(int gpu_index, rt_device** out);
+int rt_device_destroy(rt_device* dev);
+int rt_device_sync(rt_device* dev);                      /* GPUScheduler::Flush */
+void* rt_device_stream(rt_device* dev);                  /* the hipStream_t launches go to */
+int rt_device_set_stream(rt_device* dev, void* hip_stream); /* adopt a caller-owned stream (not destroyed here) */
+int rt_device_index(rt_device* dev);
+const char* rt_error_string(int code);
+
+int rt_event_create(rt_device* dev, rt_event** out);
+int rt_event_record(rt_event* ev);                       /* on the device's stream */
+int rt_event_elapsed_ms(rt_event* start, rt_event* stop, float* ms); /* synchronises on stop */
+int rt_event_destroy(rt_event* ev);
+
+/* ---- buffers: replaces StructuredBuffer / RWStructuredBuffer / UploadBuffer /
+ *      ReadbackBuffer (src/ShaderResources.h). New buffers are zero-filled, as the
+ *      reference's committed resources are (src/ShaderResources.h:2297); its result and
+ *      light buffers rely on that. ---- */
+int rt_buffer_alloc(rt_device* dev, size_t bytes, rt_buffer** out);
+int rt_buffer_wrap(rt_device* dev, void* device_ptr, size_t bytes, rt_buffer** out); /* non-owning view of caller memory */
+int rt_buffer_upload(rt_buffer* buf, const void* src, size_t bytes, size_t dst_offset);
+int rt_buffer_readback(rt_buffer* buf, void* dst, size_t bytes, size_t src_offset);  /* synchronises */
+int rt_buffer_clear(rt_buffer* buf);
+int rt_buffer_free(rt_buffer* buf);
+void* rt_buffer_ptr(rt_buffer* buf);
+size_t rt_buffer_size(rt_buffer* buf);
+
+/* ---- one launcher per compute shader, reference buffer layouts ---- */
+
+/* shader/CS_GenerateMortonCodes.hlsl (dispatch: src/RaytracerPipeline.cpp:284-303).
+ * indices: uint32[3N]; vertices: rt_vertex[]; morton: uint4[N] <- (code, 3*tri, 0, 0);
+ * code_frequencies: uint4[256], .x zeroed. */
+int rt_generate_morton_codes(rt_device* dev, const rt_morton_code_info* info, const rt_buffer* indices,
+                             const rt_buffer* vertices, rt_buffer* morton_codes, rt_buffer* code_frequencies);
+/* shader/CS_SortCount.hlsl (src/RaytracerPipeline.cpp:313-337): temp[i].xy = morton[i].xy;
+ * code_frequencies[d].x += number of keys whose digit (key >> 8*pass) & 0xff equals d. */
+int rt_sort_count(rt_device* dev, const rt_sort_info* info, const rt_buffer* morton_codes, rt_buffer* temp_morton_codes,
+                  rt_buffer* code_frequencies);
+/* shader/CS_SortPrefixSum.hlsl (src/RaytracerPipeline.cpp:339-354): .y = exclusive prefix sum of .x */
+int rt_sort_prefix_sum(rt_device* dev, const rt_sort_info* info, rt_buffer* code_frequencies);
+/* shader/CS_SortSort.hlsl (src/RaytracerPipeline.cpp:356-379): morton[].xy = temp[].xy stably partitioned
+ * by the pass's digit, starting at code_frequencies[d].y; .x of every counter is zeroed.
+ * Must follow rt_sort_count and rt_sort_prefix_sum of the same pass on the same buffers (the
+ * per-tile digit counts of the count step are kept in the device's workspace). */
+int rt_sort_sort(rt_device* dev, const rt_sort_info* info, rt_buffer* morton_codes, const rt_buffer* temp_morton_codes,
+                 rt_buffer* code_frequencies);
+/* shader/CS_BVHBuildLeaves.hlsl (src/RaytracerPipeline.cpp:483-503): info->num_children = N.
+ * Writes nodes 1 .. ceil(N/2). */
+int rt_bvh_build_leaves(rt_device* dev, const rt_bvh_info* info, const rt_buffer* indices, const rt_buffer* vertices,
+                        const rt_buffer* morton_codes, rt_buffer* bvh);
+/* shader/CS_BVHBuild.hlsl (src/RaytracerPipeline.cpp:507-559): one level. */
+int rt_bvh_build(rt_device* dev, const rt_bvh_info* info, rt_buffer* bvh);
+/* shader/CS_CameraRayGeneration.hlsl (src/RaytracerPipeline.cpp:105-150). ray_pixels: uint32 per ray
+ * ((x << 16) | y), the packing of the reference's uint4 array read as a flat uint array.
+ * first_row / num_rows restrict generation to an image band whose buffers start at row first_row
+ * (multi-GPU tiles); pass 0, screen height for the whole image. */
+int rt_camera_ray_generation(rt_device* dev, const rt_camera_ray_gen_info* info, rt_buffer* rays, rt_buffer* old_rays,
+                             rt_buffer* ray_pixels, uint32_t first_row, uint32_t num_rows);
+/* shader/CS_TraceRays.hlsl + PerRayShading.hlsli + Random.hlsli (src/RaytracerPipeline.cpp:687-729).
+ * use_bvh mirrors RT_USE_BVH (src/Settings.h:13). The hierarchy must have the layout the build
+ * launchers above emit for info->num_indices / 3 primitives. atlas: uint4[atlas_elements].
+ * first_ray is the global index of element 0 of the per-ray buffers (0 for the whole image); it
+ * enters the per-thread random seed so that image bands reproduce the single-device image. */
+int rt_trace_rays(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, const rt_buffer* indices,
+                  const rt_buffer* vertices, const rt_buffer* materials, const rt_buffer* texture_ids,
+                  const rt_buffer* texture_atlas, uint32_t atlas_elements, rt_buffer* rays, rt_buffer* old_rays,
+                  const rt_buffer* ray_pixels, rt_buffer* scattered_light, rt_buffer* emitted_light,
+                  const rt_buffer* bvh, uint32_t first_ray);
+/* shader/CS_GenerateFinalImage.hlsl (src/RaytracerPipeline.cpp:809-854). result: float4[W*H] running
+ * mean; output: float4[W*H] tone-mapped (the reference's RGBA16F texture, kept in binary32);
+ * output_half: optional uint16[4*W*H] binary16 copy, may be NULL. info->screen_dimensions[1] is
+ * the number of rows held by the buffers. */
+int rt_generate_final_image(rt_device* dev, const rt_generate_final_image_info* info, const rt_buffer* emitted_light,
+                            rt_buffer* result, rt_buffer* output, rt_buffer* output_half);
+
+/* ---- fused per-frame LBVH build (no counterpart dispatch in the reference: it replaces the
+ *      1 + 12 + ~log2(N) dependent dispatches of SortPrimitives::Sort and BuildBVH::Build,
+ *      src/RaytracerPipeline.cpp:276-383, 475-562, with identical results) ---- */
+uint32_t rt_bvh_node_count(uint32_t num_primitives);     /* nodes the hierarchy uses; 0 if < 3 primitives */
+int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out); /* allocates every workspace once */
+int rt_accel_destroy(rt_accel* accel);
+/* Gathers Indices -> Vertices -> positions into the accel's packed triangle array
+ * (3 x float4 per triangle, original order). Call after the mesh changes. */
+int rt_accel_pack(rt_accel* accel, uint32_t num_primitives, const rt_buffer* indices, const rt_buffer* vertices);
+/* Morton codes, stable sort, leaves and all levels. bvh receives rt_bvh_node_count(N) nodes, bit-identical
+ * to the per-shader launchers; morton_codes (optional, uint4[N]) receives the sorted (code, 3*tri, 0, 0). */
+int rt_accel_build(rt_accel* accel, const float scene_min[3], const float scene_max[3], rt_buffer* bvh,
+                   rt_buffer* morton_codes);
+/* rt_trace_rays reading the accel's Morton-ordered packed triangles instead of Indices -> Vertices. */
+int rt_trace_rays_accel(rt_device* dev, const rt_trace_rays_info* info, const rt_accel* accel, const rt_buffer* indices,
+                        const rt_buffer* vertices, const rt_buffer* materials, const rt_buffer* texture_ids,
+                        const rt_buffer* texture_atlas, uint32_t atlas_elements, rt_buffer* rays, rt_buffer* old_rays,
+                        const rt_buffer* ray_pixels, rt_buffer* scattered_light, rt_buffer* emitted_light,
+                        const rt_buffer* bvh, uint32_t first_ray);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

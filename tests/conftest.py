@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle_py
+    oracle_py.load()
+    return oracle_py
+
+
+@pytest.fixture(scope="session")
+def device():
+    from gpuraytracer_amd.runtime import Device
+    dev = Device(0)
+    yield dev
+    dev.close()

@@ -1,0 +1,271 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Bars: bit-exact for Morton codes, every sort pass, the sorted permutation and every hierarchy
+node; bit-exact as well for rays and shaded images wherever both sides evaluate the same binary32
+expression sequence (they are written to), with the stated tolerance as the formal bar:
+max abs error <= 1e-5 on the tone-mapped image (values in [0, 1)).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+IMAGE_TOL = 1e-5
+
+
+def _scene(n):
+    from gpuraytracer_amd import scenes
+    return scenes.synthetic_scene(n)
+
+
+def _small_scene(n_tris, seed=7):
+    """n_tris random triangles with no enclosing box (covers N = 3, 4, 5, odd counts...)."""
+    from gpuraytracer_amd import scenes
+    from gpuraytracer_amd.capi import vertex_dtype
+    rng = np.random.RandomState(seed)
+    v = np.zeros(3 * n_tris, dtype=vertex_dtype)
+    c = rng.uniform(-1, 1, (n_tris, 1, 3)).astype(np.float32)
+    v["position"] = (c + rng.uniform(-0.3, 0.3, (n_tris, 3, 3)).astype(np.float32)).reshape(-1, 3)
+    v["normal"] = (0, 0, -1)
+    v["uv"] = rng.uniform(0, 1, (3 * n_tris, 2)).astype(np.float32)
+    v["material_id"] = np.repeat(np.arange(n_tris) % 8, 3)
+    idx = np.arange(3 * n_tris, dtype=np.uint32)
+    atlas, ids = scenes.default_atlas()
+    smin, smax = scenes.centroid_bounds(v, idx)
+    cam = dict(position=(0.0, 0.0, -3.0), focus=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=1.2, near_z=0.01, far_z=10000.0)
+    return dict(vertices=v, indices=idx, materials=scenes.synthetic_materials(), texture_ids=ids, atlas=atlas, scene_min=smin,
+                scene_max=smax, camera=cam, name="small-%d" % n_tris)
+
+
+def _u4(buf, n):
+    from oracle.oracle_py import uint4_dtype
+    return buf.download(uint4_dtype, n)
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 6, 7, 255, 256, 257, 1000, 2048, 2049, 4097, 70001])
+def test_per_shader_build_matches_oracle_bit_exact(device, oracle, n):
+    """Each launcher against the oracle function of the same shader, chained on device outputs."""
+    from gpuraytracer_amd import capi
+    from gpuraytracer_amd.capi import aabb_dtype
+    lib, d = device.lib, device.handle
+    sc = _small_scene(n) if n < 1000 else _scene(n)
+    olib = oracle.load()
+    idx, vtx = device.upload(sc["indices"]), device.upload(sc["vertices"])
+    morton, temp, freq = device.alloc(16 * n), device.alloc(16 * n), device.alloc(16 * 256)
+    freq.upload(np.full(1024, 0xDEADBEEF, dtype=np.uint32))      # the Morton shader must zero .x itself
+
+    mi = capi.MortonCodeInfo()
+    omi = oracle.MortonInfo()
+    for k in range(3):
+        mi.scene_min[k] = omi.scene_min[k] = float(sc["scene_min"][k])
+        mi.scene_max[k] = omi.scene_max[k] = float(sc["scene_max"][k])
+    mi.num_primitives = omi.num_primitives = n
+    capi.check(lib.rt_generate_morton_codes(d, C.byref(mi), idx.handle, vtx.handle, morton.handle, freq.handle), "morton")
+    o_m = np.zeros(n, dtype=oracle.uint4_dtype)
+    o_t = np.zeros(n, dtype=oracle.uint4_dtype)
+    o_f = np.zeros(256, dtype=oracle.uint4_dtype)
+    o_f["x"] = 0xDEADBEEF
+    o_f["y"] = 0xDEADBEEF
+    olib.orc_generate_morton_codes(C.byref(omi), oracle.ptr(sc["indices"]), oracle.ptr(sc["vertices"]), oracle.ptr(o_m),
+                                   oracle.ptr(o_f))
+    g_m = _u4(morton, n)
+    assert np.array_equal(g_m, o_m), "Morton records differ"
+    assert np.array_equal(_u4(freq, 256)["x"], o_f["x"])
+
+    for p in range(4):
+        si, osi = capi.SortInfo(n, p), oracle.SortInfo(n, p)
+        capi.check(lib.rt_sort_count(d, C.byref(si), morton.handle, temp.handle, freq.handle), "count")
+        olib.orc_sort_count(C.byref(osi), oracle.ptr(o_m), oracle.ptr(o_t), oracle.ptr(o_f))
+        assert np.array_equal(_u4(freq, 256)["x"], o_f["x"]), "digit counts differ in pass %d" % p
+        g_t = _u4(temp, n)
+        assert np.array_equal(g_t["x"], o_t["x"]) and np.array_equal(g_t["y"], o_t["y"])
+        capi.check(lib.rt_sort_prefix_sum(d, C.byref(si), freq.handle), "prefix")
+        olib.orc_sort_prefix_sum(C.byref(osi), oracle.ptr(o_f))
+        g_f = _u4(freq, 256)
+        assert np.array_equal(g_f["y"], o_f["y"]), "prefix sums differ in pass %d" % p
+        capi.check(lib.rt_sort_sort(d, C.byref(si), morton.handle, temp.handle, freq.handle), "scatter")
+        olib.orc_sort_sort(C.byref(osi), oracle.ptr(o_m), oracle.ptr(o_t), oracle.ptr(o_f))
+        g_m = _u4(morton, n)
+        assert np.array_equal(g_m["x"], o_m["x"]) and np.array_equal(g_m["y"], o_m["y"]), "scatter differs in pass %d" % p
+        assert np.array_equal(_u4(freq, 256)["x"], o_f["x"])
+    # structural invariant: the result is the stable sort of (code, 3*tri) by code
+    codes = g_m["x"].astype(np.int64)
+    assert np.all(np.diff(codes) >= 0)
+    ties = np.diff(codes) == 0
+    assert np.all(np.diff(g_m["y"].astype(np.int64))[ties] > 0)
+
+    nodes = oracle.load().orc_bvh_node_count(n)
+    assert nodes == lib.rt_bvh_node_count(n)
+    bvh = device.alloc(32 * max(nodes, 1))
+    o_bvh = np.zeros(nodes, dtype=aabb_dtype)
+    bi, obi = capi.BVHInfo(n, 1, (n + 1) // 2 + 1, 0), oracle.BvhInfo(n, 1, (n + 1) // 2 + 1, 0)
+    capi.check(lib.rt_bvh_build_leaves(d, C.byref(bi), idx.handle, vtx.handle, morton.handle, bvh.handle), "leaves")
+    olib.orc_bvh_build_leaves(C.byref(obi), oracle.ptr(sc["indices"]), oracle.ptr(sc["vertices"]), oracle.ptr(o_m),
+                              oracle.ptr(o_bvh))
+    nc, prev, cur = (n + 1) // 2, 1, (n + 1) // 2 + 1
+    while nc != 2:
+        bi, obi = capi.BVHInfo(nc, prev, cur, 0), oracle.BvhInfo(nc, prev, cur, 0)
+        capi.check(lib.rt_bvh_build(d, C.byref(bi), bvh.handle), "level")
+        olib.orc_bvh_build(C.byref(obi), oracle.ptr(o_bvh))
+        nc = (nc + 1) // 2
+        prev, cur = cur, cur + nc
+    bi, obi = capi.BVHInfo(2, prev, 0, 0), oracle.BvhInfo(2, prev, 0, 0)
+    capi.check(lib.rt_bvh_build(d, C.byref(bi), bvh.handle), "root")
+    olib.orc_bvh_build(C.byref(obi), oracle.ptr(o_bvh))
+    assert cur == nodes
+    g_bvh = bvh.download(aabb_dtype, nodes)
+    assert g_bvh.tobytes() == o_bvh.tobytes(), "hierarchy nodes differ"
+    for b in (idx, vtx, morton, temp, freq, bvh):
+        b.free()
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 511, 513, 1000, 4099, 131073, 1000000])
+def test_fused_build_matches_oracle_bit_exact(device, oracle, n):
+    from gpuraytracer_amd.capi import aabb_dtype
+    from gpuraytracer_amd.runtime import Accel
+    sc = _small_scene(n) if n < 1000 else _scene(n)
+    o_m = oracle.sort_primitives(sc)
+    o_bvh, count = oracle.build_bvh(sc, o_m)
+    idx, vtx = device.upload(sc["indices"]), device.upload(sc["vertices"])
+    acc = Accel(device, n)
+    acc.pack(n, idx, vtx)
+    bvh, morton = device.alloc(32 * count), device.alloc(16 * n)
+    for _ in range(2):                                   # a rebuild must give the same result
+        acc.build(sc["scene_min"], sc["scene_max"], bvh, morton)
+        g_m = _u4(morton, n)
+        assert np.array_equal(g_m, o_m), "sorted Morton records differ"
+        assert bvh.download(aabb_dtype, count).tobytes() == o_bvh[:count].tobytes(), "hierarchy nodes differ"
+    acc.destroy()
+    for b in (idx, vtx, bvh, morton):
+        b.free()
+
+
+def test_too_few_primitives_is_an_error(device):
+    from gpuraytracer_amd import capi
+    assert device.lib.rt_bvh_node_count(2) == 0
+    h = C.c_void_p()
+    assert device.lib.rt_accel_create(device.handle, 2, C.byref(h)) == capi.RT_ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("w,h,rpp,dof", [(64, 36, 1, 0.0), (130, 50, 2, 1.0), (17, 9, 3, 0.5)])
+def test_camera_rays_match_oracle(device, oracle, w, h, rpp, dof):
+    from gpuraytracer_amd import capi
+    from gpuraytracer_amd.capi import ray_dtype
+    iv, ip = oracle.camera_matrices((-4.0259, 2.1676, -2.9459), (0, 0, 0), (0, 1, 0), 1.2, w / h, 0.01, 10000.0)
+    info, oinfo = capi.CameraRayGenInfo(), oracle.RaygenInfo()
+    for k in range(16):
+        info.inverse_view[k] = oinfo.inverse_view[k] = float(iv[k])
+        info.inverse_projection[k] = oinfo.inverse_projection[k] = float(ip[k])
+    info.screen_size[0] = oinfo.screen[0] = w
+    info.screen_size[1] = oinfo.screen[1] = h
+    info.aa_sample_spread = oinfo.aa_spread = 1.5
+    info.dof_sample_spread = oinfo.dof_spread = dof
+    info.max_rays_per_pixel = oinfo.max_rays_per_pixel = rpp
+    for k, s in enumerate((123456789, 362436069, 521288629)):
+        info.rng_seed[k] = oinfo.rng_seed[k] = s
+    n = w * h * rpp
+    rays, old, pix = device.alloc(32 * n), device.alloc(32 * n), device.alloc(4 * n)
+    capi.check(device.lib.rt_camera_ray_generation(device.handle, C.byref(info), rays.handle, old.handle, pix.handle, 0, h), "raygen")
+    o_r, o_o, o_p = np.zeros(n, dtype=ray_dtype), np.zeros(n, dtype=ray_dtype), np.zeros(n, dtype=np.uint32)
+    oracle.load().orc_camera_ray_generation(C.byref(oinfo), oracle.ptr(o_r), oracle.ptr(o_o), oracle.ptr(o_p))
+    assert np.array_equal(pix.download(np.uint32, n), o_p)
+    assert old.download(ray_dtype, n).tobytes() == o_o.tobytes()
+    g_r = rays.download(ray_dtype, n)
+    assert g_r.tobytes() == o_r.tobytes(), "camera rays differ"
+    # unit test of the camera convention: with depth of field off every ray starts near the camera position
+    if dof == 0.0:
+        assert np.abs(g_r["origin"] - np.array([-4.0259, 2.1676, -2.9459], dtype=np.float32)).max() < 0.05
+    # a band of rows reproduces the same rays
+    r0, nrows = h // 3, h // 2
+    nb = w * nrows * rpp
+    rb, ob, pb = device.alloc(32 * nb), device.alloc(32 * nb), device.alloc(4 * nb)
+    capi.check(device.lib.rt_camera_ray_generation(device.handle, C.byref(info), rb.handle, ob.handle, pb.handle, r0, nrows), "band")
+    assert rb.download(ray_dtype, nb).tobytes() == o_r[r0 * w * rpp:(r0 + nrows) * w * rpp].tobytes()
+    assert np.array_equal(pb.download(np.uint32, nb), o_p[r0 * w * rpp:(r0 + nrows) * w * rpp])
+    for b in (rays, old, pix, rb, ob, pb):
+        b.free()
+
+
+def _render_both(device, oracle, sc, w, h, calls, rpp=1, depth=3, use_bvh=True, use_accel=True, dof=0.0):
+    from gpuraytracer_amd.pipeline import Pipeline
+    cam = sc["camera"]
+    iv, ip = oracle.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], w / h, cam["near_z"], cam["far_z"])
+    ncycles = (calls + depth - 1) // depth
+    rs = oracle.mt19937(1, 0, 3 * ncycles + 3).reshape(-1, 3)
+    ts = oracle.mt19937(2, 0, 3 * calls + 3).reshape(-1, 3)
+    ri, ti = iter(rs), iter(ts)
+    gp = Pipeline(device, sc, w, h, iv, ip, rpp=rpp, depth=depth, dof=dof, use_bvh=use_bvh, use_accel=use_accel,
+                  raygen_seeds=lambda: next(ri), trace_seeds=lambda: next(ti))
+    op = oracle.Pipeline(sc, w, h, rpp=rpp, depth=depth, dof=dof, use_bvh=use_bvh, seed_raygen=1, seed_trace=2)
+    gp.render(calls)
+    op.render(calls)
+    out = (gp.output_image(), op.output(), gp.result_image(), op.result(),
+           gp.emitted.download(np.float32, 4 * w * h * rpp).reshape(-1, 4), op.emitted(),
+           gp.rays.download(np.float32, 8 * w * h * rpp).reshape(-1, 8), op.rays().view(np.float32).reshape(-1, 8))
+    gp.close()
+    op.close()
+    return out
+
+
+def _report(name, g, o):
+    diff = np.abs(g.astype(np.float64) - o.astype(np.float64))
+    diff = np.nan_to_num(diff, nan=0.0)
+    exact = np.mean(g.view(np.uint32) == o.view(np.uint32))
+    mse = float((diff ** 2).mean())
+    psnr = 99.0 if mse == 0 else 10 * np.log10(1.0 / mse)
+    print("%s: max abs %.3g, bit-identical %.5f%%, PSNR %.1f dB" % (name, diff.max(), 100 * exact, psnr))
+    return diff.max(), exact
+
+
+@pytest.mark.parametrize("n,w,h,calls,use_accel", [(1000, 96, 54, 6, True), (1000, 96, 54, 6, False), (20000, 160, 90, 9, True),
+                                                   (20000, 64, 36, 3, False)])
+def test_traced_images_match_oracle(device, oracle, n, w, h, calls, use_accel):
+    sc = _scene(n)
+    g_out, o_out, g_res, o_res, g_em, o_em, g_rays, o_rays = _render_both(device, oracle, sc, w, h, calls, use_accel=use_accel)
+    assert np.isfinite(o_out).all()
+    m1, _ = _report("tone-mapped", g_out, o_out)
+    _report("result", g_res, o_res)
+    _report("emitted", g_em, o_em)
+    _report("rays", g_rays, o_rays)
+    assert m1 <= IMAGE_TOL
+    assert o_out[..., :3].max() > 0.0, "the test image must not be black"
+
+
+def test_traced_image_without_bvh_matches_oracle(device, oracle):
+    sc = _scene(300)
+    g_out, o_out = _render_both(device, oracle, sc, 48, 27, 6, use_bvh=False)[:2]
+    m1, _ = _report("no-BVH tone-mapped", g_out, o_out)
+    assert m1 <= IMAGE_TOL
+
+
+def test_multiple_rays_per_pixel_and_dof(device, oracle):
+    sc = _scene(5000)
+    g_out, o_out = _render_both(device, oracle, sc, 40, 30, 8, rpp=3, depth=4, dof=1.0)[:2]
+    m1, _ = _report("rpp=3 dof=1 tone-mapped", g_out, o_out)
+    assert m1 <= IMAGE_TOL
+
+
+def test_image_bands_reproduce_the_full_image(device, oracle):
+    """Two half-image pipelines (global pixel/ray indices in the seeds) assemble to the full image."""
+    from gpuraytracer_amd.pipeline import Pipeline
+    sc = _scene(4000)
+    w, h, calls = 64, 40, 6
+    cam = sc["camera"]
+    iv, ip = oracle.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], w / h, cam["near_z"], cam["far_z"])
+    rs = oracle.mt19937(1, 0, 30).reshape(-1, 3)
+    ts = oracle.mt19937(2, 0, 30).reshape(-1, 3)
+
+    def run(first, rows):
+        ri, ti = iter(rs), iter(ts)
+        p = Pipeline(device, sc, w, h, iv, ip, raygen_seeds=lambda: next(ri), trace_seeds=lambda: next(ti), first_row=first,
+                     num_rows=rows)
+        p.render(calls)
+        img = p.output_image()
+        p.close()
+        return img
+
+    full = run(0, h)
+    top, bottom = run(0, 17), run(17, h - 17)
+    assert np.array_equal(np.concatenate([top, bottom], axis=0).view(np.uint32), full.view(np.uint32))
