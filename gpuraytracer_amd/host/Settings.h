@@ -1,0 +1,66 @@
+#pragma once
+// Compile-time defaults under the reference's macro names (src/Settings.h:4-35 of the reference) and a
+// run-time copy of them, so that one binary can run every benchmark configuration.
+// The reference's macros carry stray semicolons and brace initialisers that only work in the
+// declarations they were written for; the values are the same here, the form is plain.
+
+#include <cstdint>
+#include <string>
+
+//window size (now: size of the headless image)
+#define RT_WINDOW_WIDTH 1280
+#define RT_WINDOW_HEIGHT 720
+
+//raytracing properties
+#define RT_SCENE_FILENAME "assets/testscene1.obj"
+#define RT_MAX_RAYS_PER_PIXEL 1
+#define RT_MAX_RAY_DEPTH 3
+#define RT_AA_SAMPLE_SPREAD 1.5f
+#define RT_DOF_SAMPLE_SPREAD 0.0f
+#define RT_USE_BVH 1
+#define RT_MAX_TIME 1e30f
+#define RT_MAX_SECONDS 600.0f
+
+//camera settings
+#define RT_CAMERA_FOV 1.2f
+#define RT_CAMERA_NEARZ 0.01f
+#define RT_CAMERA_FARZ 10000.0f
+
+//for testscene1.obj (for testscene2.obj: position 0,0,0 focus 1,0,0; for testobject4_2.obj: position -2.5,5,-2)
+#define RT_CAMERA_POSITION_X -4.0259f
+#define RT_CAMERA_POSITION_Y 2.1676f
+#define RT_CAMERA_POSITION_Z -2.9459f
+#define RT_CAMERA_FOCUS_POINT_X 0.0f
+#define RT_CAMERA_FOCUS_POINT_Y 0.0f
+#define RT_CAMERA_FOCUS_POINT_Z 0.0f
+#define RT_CAMERA_UP_DIRECTION_X 0.0f
+#define RT_CAMERA_UP_DIRECTION_Y 1.0f
+#define RT_CAMERA_UP_DIRECTION_Z 0.0f
+
+namespace RT
+{
+	struct Settings
+	{
+		uint32_t WindowWidth = RT_WINDOW_WIDTH;
+		uint32_t WindowHeight = RT_WINDOW_HEIGHT;
+		std::string SceneFilename = RT_SCENE_FILENAME;
+		uint32_t MaxRaysPerPixel = RT_MAX_RAYS_PER_PIXEL;
+		uint32_t MaxRayDepth = RT_MAX_RAY_DEPTH;
+		float AASampleSpread = RT_AA_SAMPLE_SPREAD;
+		float DOFSampleSpread = RT_DOF_SAMPLE_SPREAD;
+		bool UseBVH = RT_USE_BVH != 0;
+		float MaxSeconds = RT_MAX_SECONDS;
+		float CameraFOV = RT_CAMERA_FOV;
+		float CameraNearZ = RT_CAMERA_NEARZ;
+		float CameraFarZ = RT_CAMERA_FARZ;
+		float CameraPosition[3] = { RT_CAMERA_POSITION_X, RT_CAMERA_POSITION_Y, RT_CAMERA_POSITION_Z };
+		float CameraFocusPoint[3] = { RT_CAMERA_FOCUS_POINT_X, RT_CAMERA_FOCUS_POINT_Y, RT_CAMERA_FOCUS_POINT_Z };
+		float CameraUpDirection[3] = { RT_CAMERA_UP_DIRECTION_X, RT_CAMERA_UP_DIRECTION_Y, RT_CAMERA_UP_DIRECTION_Z };
+
+		//additions of the headless build
+		bool RebuildBVHEveryCycle = false;  //the reference builds once; true = per-frame rebuild
+		bool FusedBuild = true;             //one fused LBVH build instead of one launch per reference dispatch
+		uint32_t SeedRayGen = 0;            //std::mt19937 seeds of the two host generators; 0 = std::random_device
+		uint32_t SeedTrace = 0;
+	};
+}

@@ -1,0 +1,211 @@
+"""CPU tests of the host side: library symbols, the from-scratch OBJ/MTL/PNG loaders against what the
+reference's vendored parsers return (tests/golden/ref_*.npz), camera matrices, atlas packing, the
+synthetic scene generator, band sharding. No GPU compute is called."""
+import ctypes as C
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF_ASSETS = "/root/reference/assets"
+needs_reference_assets = pytest.mark.skipif(not os.path.isdir(REF_ASSETS), reason="the reference's asset files are not on this machine")
+
+
+def test_library_exports_every_declared_symbol():
+    from gpuraytracer_amd import capi
+    lib = capi.load()
+    header = open(os.path.join(ROOT, "include", "gpurt.h")).read()
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 30
+    assert declared == set(capi.SIGNATURES), "include/gpurt.h and the ctypes table disagree"
+    for name in declared:
+        assert hasattr(lib, name), "libgpurt.so does not export %s" % name
+
+
+def test_error_strings_and_struct_sizes():
+    from gpuraytracer_amd import capi
+    assert capi.error_string(0) == "ok"
+    assert capi.error_string(capi.RT_ERR_TOO_FEW_PRIMITIVES) == "fewer than 3 primitives"
+    lib = capi.load()
+    assert lib.rt_bvh_node_count(992) == 992 and lib.rt_bvh_node_count(2) == 0 and lib.rt_bvh_node_count(50000000) == 50000007
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from gpuraytracer_amd import capi
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libgpurt.so")
+    with pytest.raises(capi.GpurtMissing):
+        capi.load()
+
+
+def test_parse_real_follows_the_digit_accumulation_rule():
+    from gpuraytracer_amd import host_py
+    cases = ["3.793523", "-1.000000", "0.375000", "867.454773", "1e-3", "-.5", "+2.5E+2", "0.0000001234", "12", "7.", "abc"]
+    for text in cases:
+        got = host_py.parse_real(text)
+        try:
+            want = np.float32(float(text))
+        except ValueError:
+            want = np.float32(0.0)
+        assert abs(got - want) <= abs(want) * 2e-7, text
+    assert host_py.parse_real("0.1") == np.float32(0.1)
+
+
+@needs_reference_assets
+@pytest.mark.parametrize("name", ["testobject4_2", "testobject5_1", "testscene2"])
+def test_obj_loader_matches_the_reference_parser(name, oracle):
+    from gpuraytracer_amd import host_py
+    g = np.load(os.path.join(GOLD, "ref_mesh_%s.npz" % name))
+    cwd = os.getcwd()
+    os.chdir("/root/reference")           # texture paths in the MTL are relative to the reference's working directory
+    try:
+        sc = host_py.load_scene("assets/%s.obj" % name)
+    finally:
+        os.chdir(cwd)
+    v = sc["vertices"]
+    assert len(v) == len(g["corners"]) and np.array_equal(sc["indices"], np.arange(len(v)))
+    assert np.array_equal(v["position"].view(np.uint32), g["corners"][:, 0:3].view(np.uint32)), "positions differ in some bit"
+    assert np.array_equal(v["uv"].view(np.uint32), g["corners"][:, 3:5].view(np.uint32))
+    assert np.array_equal(v["normal"].view(np.uint32), g["corners"][:, 5:8].view(np.uint32))
+    assert np.array_equal(v["material_id"], g["material_ids"].astype(np.uint32))
+    m, mtl = sc["materials"], g["mtl"]
+    assert len(m) == len(mtl)
+    assert np.array_equal(m["albedo"], mtl[:, 0:3]) and np.array_equal(m["f0_color"], mtl[:, 3:6])
+    assert np.array_equal(m["emissive"], mtl[:, 6:9]) and np.array_equal(m["metallic"], mtl[:, 11])
+    lib = oracle.load()
+    want_rough = np.array([lib.orc_roughness_from_mtl(float(r[9]), float(r[10])) for r in mtl], dtype=np.float32)
+    assert np.array_equal(m["roughness"], want_rough)
+    # texture table order: "" first, then first appearance
+    names = [""]
+    for row in g["texture_names"]:
+        for t in row:
+            if t not in names:
+                names.append(str(t))
+    assert sc["texture_names"] == names
+    # post-processing against the oracle's restatement of the same host code
+    o = np.load(os.path.join(GOLD, "oracle_%s.npz" % name))
+    assert np.array_equal(sc["scene_min"], o["scene_min"]) and np.array_equal(sc["scene_max"], o["scene_max"])
+    assert np.array_equal(v["tangent"].view(np.uint32), o["vertices"]["tangent"].view(np.uint32))
+    assert sc["materials"].tobytes() == o["materials"].tobytes()
+    assert sc["texture_ids"].tobytes() == o["texture_ids"].tobytes()
+    if "atlas" in o:
+        assert np.array_equal(sc["atlas"], o["atlas"])
+    else:
+        t = np.load(os.path.join(GOLD, "ref_texture_Testure1.npz"))
+        a = sc["atlas"].reshape(-1).view(np.uint8)
+        assert len(a) == 16 + 1024 * 1024 * 8 and np.all(a[:8] == 0xFF) and np.all(a[8 + 1024 * 1024 * 8:] == 0)
+        px = a[8:8 + 1024 * 1024 * 8].view(np.uint16).reshape(1024, 1024, 4)
+        assert np.array_equal(px[..., :3], t["rgb8"].astype(np.uint16) * 257) and np.all(px[..., 3] == 65535)
+        assert tuple(sc["texture_ids"][1]) == (16, 1024, 1024, 1024)      # byte offset, as the reference stores it
+
+
+@needs_reference_assets
+def test_png_decoder_matches_the_reference_decoder():
+    from gpuraytracer_amd import host_py
+    t = np.load(os.path.join(GOLD, "ref_texture_Testure1.npz"))
+    px = host_py.load_texture(os.path.join(REF_ASSETS, "Testure1.png"))
+    assert px.shape == (1024, 1024, 4)
+    assert np.array_equal(px[0, 0], t["first_texel"]) and list(px[0, 0]) == [52171, 43176, 8738, 65535]
+    assert np.array_equal(px[..., :3], t["rgb8"].astype(np.uint16) * 257) and np.all(px[..., 3] == 65535)
+
+
+@pytest.mark.parametrize("mode,bits", [("RGB", 8), ("RGBA", 8), ("L", 8), ("LA", 8), ("P", 8), ("I;16", 16)])
+def test_png_decoder_on_generated_files(tmp_path, mode, bits):
+    from PIL import Image
+    from gpuraytracer_amd import host_py
+    rng = np.random.RandomState(11)
+    w, h = 37, 23
+    if mode == "I;16":
+        data = rng.randint(0, 65536, (h, w)).astype(np.uint16)
+        im = Image.fromarray(data, mode="I;16")
+        want = np.stack([data, data, data, np.full_like(data, 65535)], axis=2)
+    elif mode == "P":
+        idx = rng.randint(0, 16, (h, w)).astype(np.uint8)
+        pal = rng.randint(0, 256, (16, 3)).astype(np.uint8)
+        im = Image.fromarray(idx, mode="P")
+        im.putpalette(pal.reshape(-1).tolist())
+        rgb = pal[idx].astype(np.uint16) * 257
+        want = np.concatenate([rgb, np.full((h, w, 1), 65535, dtype=np.uint16)], axis=2)
+    else:
+        ch = len(mode)
+        data = rng.randint(0, 256, (h, w, ch)).astype(np.uint8)
+        im = Image.fromarray(data[..., 0] if ch == 1 else data, mode=mode)
+        d16 = data.astype(np.uint16) * 257
+        if mode == "L":
+            want = np.concatenate([d16, d16, d16, np.full((h, w, 1), 65535, dtype=np.uint16)], axis=2)
+        elif mode == "LA":
+            want = np.concatenate([d16[..., :1]] * 3 + [d16[..., 1:2]], axis=2)
+        elif mode == "RGB":
+            want = np.concatenate([d16, np.full((h, w, 1), 65535, dtype=np.uint16)], axis=2)
+        else:
+            want = d16
+    path = str(tmp_path / "t.png")
+    im.save(path)
+    got = host_py.load_texture(path)
+    assert np.array_equal(got, want)
+
+
+def test_loader_rejects_bad_input(tmp_path):
+    from gpuraytracer_amd import host_py
+    with pytest.raises(RuntimeError):
+        host_py.load_scene(str(tmp_path / "missing.obj"))
+    quad = tmp_path / "quad.obj"
+    quad.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\nf 1/1/1 2/1/1 3/1/1 4/1/1\n")
+    with pytest.raises(RuntimeError):
+        host_py.load_scene(str(quad))
+    with pytest.raises(RuntimeError):
+        host_py.load_texture(str(quad))
+
+
+def test_loader_without_materials_or_normals(tmp_path):
+    """No MTL: one glowing default material; missing normals are generated; negative indices resolve."""
+    from gpuraytracer_amd import host_py
+    p = tmp_path / "tri.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nvt 0 0\nvt 1 0\nvt 0 1\nf 1/1 2/2 3/3\nf -4/1 -2/3 -1/2\n")
+    sc = host_py.load_scene(str(p))
+    assert len(sc["vertices"]) == 6 and len(sc["materials"]) == 1
+    assert tuple(sc["materials"][0]["emissive"]) == (0.5, 0.5, 0.5)
+    assert np.all(sc["vertices"]["material_id"] == 0xFFFFFFFF)        # tinyobj's "no material" id, kept as the reference keeps it
+    n = sc["vertices"]["normal"]
+    assert np.allclose(np.abs(n[0]), (0, 0, 1)) and np.allclose(np.linalg.norm(n, axis=1), 1.0)
+    assert np.array_equal(sc["vertices"]["position"][3], (0, 0, 0)) and np.array_equal(sc["vertices"]["position"][5], (0, 0, 1))
+    assert sc["texture_names"] == [""] and len(sc["texture_ids"]) == 1 and sc["atlas"].shape == (1, 4)
+
+
+def test_camera_matrices_match_the_oracle(oracle):
+    from gpuraytracer_amd import host_py
+    for pos, focus, aspect in [((-4.0259, 2.1676, -2.9459), (0, 0, 0), 1280 / 720), ((0, 0, 0), (1, 0, 0), 16 / 9),
+                               ((0, 0, -22), (0, 0, 0), 3840 / 2160), ((-2.5, 5.0, -2.0), (0, 0, 0), 1.0)]:
+        a = host_py.camera_matrices(pos, focus, (0, 1, 0), 1.2, aspect, 0.01, 10000.0)
+        b = oracle.camera_matrices(pos, focus, (0, 1, 0), 1.2, aspect, 0.01, 10000.0)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        # inverse(transpose(V)) read column-major is V^-1: its last row (row-vector convention) is the camera position
+        vinv = a[0].reshape(4, 4).T
+        assert np.allclose(vinv[3, :3], pos, atol=1e-5) and np.allclose(vinv[:, 3], (0, 0, 0, 1), atol=1e-6)
+
+
+def test_synthetic_scene_generators_agree():
+    from gpuraytracer_amd import host_py, scenes
+    for n in (15, 1000, 20011):
+        a, b = scenes.synthetic_scene(n), host_py.synthetic_scene(n)
+        assert a["vertices"].tobytes() == b["vertices"].tobytes()
+        assert np.array_equal(a["indices"], b["indices"]) and a["materials"].tobytes() == b["materials"].tobytes()
+        assert np.array_equal(a["scene_min"], b["scene_min"]) and np.array_equal(a["scene_max"], b["scene_max"])
+        assert np.array_equal(a["atlas"], b["atlas"]) and a["texture_ids"].tobytes() == b["texture_ids"].tobytes()
+    with pytest.raises(ValueError):
+        host_py.synthetic_scene(14)
+
+
+def test_band_partition_covers_the_image():
+    from gpuraytracer_amd.distributed import band_for_rank
+    for h in (1, 7, 720, 2160, 4320):
+        for world in (1, 2, 3, 4, 8):
+            rows = [band_for_rank(h, world, r) for r in range(world)]
+            assert rows[0][0] == 0 and sum(n for _, n in rows) == h
+            for (f0, n0), (f1, _) in zip(rows, rows[1:]):
+                assert f0 + n0 == f1
+            assert max(n for _, n in rows) - min(n for _, n in rows) <= 1
