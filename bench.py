@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Benchmark of the LBVH-build + ray-trace hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one frame of the workload: rebuild the LBVH (Morton codes, radix sort, leaves, levels),
+generate camera rays, trace `depth` bounces (each followed by the final-image pass), and - with more
+than one GPU - gather the image bands to rank 0. Inputs are resident in HBM before the timed region.
+Default workload ("c3"): the 1M-triangle synthetic scene at 3840x2160, 1 ray per pixel, 4 bounces,
+LBVH rebuilt every frame. With N GPUs the image is cut into N bands of rows (strong scaling: the
+frame is fixed), the scene and hierarchy are replicated and rebuilt on every GPU.
+
+Rank 0 prints ONE JSON line: Mrays/s over the whole job (a ray = one ray segment handled by one trace
+thread in one trace launch), the LBVH build time, a roofline object for the dominant kernel (the
+trace kernel; algorithmic bytes from exact traversal counters) and the CPU baseline (the scalar
+OpenMP oracle timed on a bounded sample of the same workload on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak
+BUILD_BYTES_PER_TRIANGLE = 252  # Morton 56 + sort 80 + leaves 68 + upper levels 48 (reference data layout)
+
+WORKLOADS = {
+    # name: (triangles, width, height, rays/pixel, bounces, description)
+    "c3": (1000000, 3840, 2160, 1, 4, "C3: synthetic 1M-triangle scene, 3840x2160, 1 ray/pixel, 4 bounces, LBVH rebuilt every frame"),
+    "c4": (10000000, 3840, 2160, 1, 4, "C4: synthetic 10M-triangle scene, 3840x2160, 1 ray/pixel, 4 bounces, LBVH rebuilt every frame"),
+    "small": (100000, 1280, 720, 1, 3, "small: synthetic 100k-triangle scene, 1280x720, 1 ray/pixel, 3 bounces, LBVH rebuilt every frame"),
+}
+
+
+def trace_bytes(rays, hits, nodes, tris):
+    """Algorithmic bytes of trace launches in the reference's data layout: 100 B of per-ray state read,
+    96 B written on a hit (ray, previous ray, two light values) or 32 B on a miss, 32 B per box test,
+    12 + 36 B per triangle test, and on a hit three 48-B vertices, a 64-B material and five texture
+    lookups of 16 + 8 B."""
+    return rays * 100 + hits * (96 + 3 * 48 + 64 + 5 * 24) + (rays - hits) * 32 + nodes * 32 + tris * 48
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--triangles", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-div", type=int, default=4, help="CPU baseline traces the image reduced by this factor per axis")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from gpuraytracer_amd import host_py, scenes
+    from gpuraytracer_amd.distributed import band_for_rank, gather_bands
+    from gpuraytracer_amd.pipeline import Pipeline
+    from gpuraytracer_amd.runtime import Device
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed launcher (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ntri, width, height, rpp, depth, desc = WORKLOADS[args.workload]
+    ntri = args.triangles or ntri
+    width = args.width or width
+    height = args.height or height
+
+    # scene, camera and host seeds come from the product's own host code (C++ generator and camera maths)
+    scene = host_py.synthetic_scene(ntri)
+    cam = scene["camera"]
+    iv, ip = host_py.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], width / height, cam["near_z"],
+                                     cam["far_z"])
+    total_frames = args.steps + args.warmup + 2
+    rs = iter(scenes.mt19937_raw(1, 3 * total_frames).reshape(-1, 3))
+    ts = iter(scenes.mt19937_raw(2, 3 * total_frames * depth).reshape(-1, 3))
+
+    first_row, num_rows = band_for_rank(height, world, rank)
+    stream = torch.cuda.Stream()
+    dev = Device(local_rank)
+    with torch.cuda.stream(stream):
+        dev.set_stream(stream.cuda_stream)
+        band = torch.zeros((num_rows, width, 4), dtype=torch.float32, device="cuda")
+        pipe = Pipeline(dev, scene, width, height, iv, ip, rpp=rpp, depth=depth, use_bvh=True, use_accel=True,
+                        raygen_seeds=lambda: next(rs), trace_seeds=lambda: next(ts), first_row=first_row, num_rows=num_rows,
+                        rebuild_every_cycle=True, output_ptr=band.data_ptr())
+
+        build_events, trace_events = [], []
+        raw_build, raw_trace = pipe.build, pipe.trace
+        timing = {"on": False}
+
+        def timed(fn, store):
+            def call():
+                if not timing["on"]:
+                    return fn()
+                a, b = dev.event(), dev.event()
+                a.record()
+                fn()
+                b.record()
+                store.append((a, b))
+            return call
+
+        pipe.build = timed(raw_build, build_events)
+        pipe.trace = timed(raw_trace, trace_events)
+
+        def step():
+            pipe.render(depth)                       # one frame: build, camera rays, `depth` bounces
+            if world > 1:
+                return gather_bands(band, height, width)
+            return band
+
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        timing["on"] = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        timing["on"] = False
+
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        build_ms = [a.elapsed_ms(b) for a, b in build_events]
+        trace_ms = [a.elapsed_ms(b) for a, b in trace_events]
+
+        # exact traversal counters of one more frame (untimed, instrumented kernel variant)
+        stats_buf = dev.alloc(32)
+        dev.lib.rt_device_set_trace_stats(dev.handle, stats_buf.handle)
+        pipe.render(depth)
+        dev.sync()
+        dev.lib.rt_device_set_trace_stats(dev.handle, None)
+        nodes, tris, hits, counted = [int(x) for x in stats_buf.download(np.uint64, 4)]
+        img = band.float().cpu().numpy()
+
+    local_rays = num_rows * width * rpp
+    rays_per_step = width * height * rpp * depth
+    mrays = rays_per_step * args.steps / elapsed / 1e6
+    launches_per_frame = depth
+    bytes_per_launch = trace_bytes(counted, hits, nodes, tris) / launches_per_frame
+    avg_trace_s = float(np.mean(trace_ms)) * 1e-3
+    achieved = bytes_per_launch / avg_trace_s / 1e9
+    avg_build_ms = float(np.mean(build_ms))
+
+    out = {
+        "metric": "Mrays/sec", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc if not (args.triangles or args.width or args.height) else
+                   "custom: synthetic %d-triangle scene, %dx%d, %d ray/pixel, %d bounces, LBVH rebuilt every frame" % (ntri, width, height, rpp, depth),
+                   "triangles": ntri, "width": width, "height": height, "rays_per_pixel": rpp, "bounces": depth,
+                   "parallelism": "image bands x%d, replicated scene + per-GPU rebuild, gather to rank 0" % world},
+        "lbvh_build_ms": round(avg_build_ms, 4),
+        "roofline": {"kernel": "k_trace", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "avg_launch_ms": round(avg_trace_s * 1e3, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                     "rays_per_launch": local_rays, "box_tests_per_ray": round(nodes / max(counted, 1), 2),
+                     "triangle_tests_per_ray": round(tris / max(counted, 1), 3), "hit_fraction": round(hits / max(counted, 1), 4)},
+        "build_roofline": {"kernels": "k_morton_packed + 4 x (k_sort_hist, k_sort_scan, k_sort_scatter) + k_leaves + k_upsweep",
+                           "bound": "hbm", "achieved": round(BUILD_BYTES_PER_TRIANGLE * ntri / (avg_build_ms * 1e-3) / 1e9, 2),
+                           "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": round(BUILD_BYTES_PER_TRIANGLE * ntri / (avg_build_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                           "algorithmic_bytes_per_triangle": BUILD_BYTES_PER_TRIANGLE},
+        "image_mean": round(float(img[..., :3].mean()), 6),
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline: the oracle (scalar OpenMP restatement of the reference shaders) on a bounded sample -
+        # the same scene and camera, the image reduced per axis, one frame including its build
+        from oracle import oracle_py as oracle
+        div = max(args.cpu_sample_div, 1)
+        cw, ch = max(width // div, 16), max(height // div, 9)
+        tb = time.perf_counter()
+        m = oracle.sort_primitives(scene)
+        oracle.build_bvh(scene, m)
+        cpu_build_ms = (time.perf_counter() - tb) * 1e3
+        op = oracle.Pipeline(scene, cw, ch, rpp=rpp, depth=depth, seed_raygen=1, seed_trace=2)
+        tt = time.perf_counter()
+        op.render(depth)
+        cpu_s = time.perf_counter() - tt - cpu_build_ms * 1e-3      # render() includes one build
+        _, tot = op.stats()
+        op.close()
+        out["cpu_baseline"] = {"value": round(cw * ch * rpp * depth / max(cpu_s, 1e-9) / 1e6, 4), "unit": "Mrays/s",
+                               "cores": oracle.load().orc_num_threads(), "kind": "port",
+                               "sample": "one frame of the same scene and camera at %dx%d (1/%d of the rays), %d bounces; "
+                                         "LBVH build of the full %d triangles timed separately" % (cw, ch, div * div, depth, ntri),
+                               "lbvh_build_ms": round(cpu_build_ms, 2),
+                               "box_tests_per_ray": round(tot["nodes_visited"] / max(tot["rays"], 1), 2)}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    pipe.close()
+    dev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

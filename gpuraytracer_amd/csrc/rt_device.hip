@@ -23,6 +23,7 @@ int rt_device_create(int gpu_index, rt_device** out) {
     d->sort_table = nullptr;
     d->sort_table_words = 0;
     d->sort_totals = nullptr;
+    d->trace_stats = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete d; return RT_ERR_HIP_BASE + (int)e; }
     e = hipMalloc((void**)&d->sort_totals, 512 * sizeof(uint32_t));

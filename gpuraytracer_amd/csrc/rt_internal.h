@@ -15,6 +15,7 @@ struct rt_device {
     uint32_t* sort_table;      // [256][tiles], digit-major
     size_t sort_table_words;
     uint32_t* sort_totals;     // [256] digit totals + [256] exclusive digit bases
+    unsigned long long* trace_stats;   // optional traversal counters (rt_device_set_trace_stats)
 };
 
 struct rt_buffer {

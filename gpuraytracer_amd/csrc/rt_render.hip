@@ -219,14 +219,15 @@ __device__ __forceinline__ f3 vpos(const rt_vertex* __restrict__ verts, uint32_t
 
 // One thread per ray. USE_BVH mirrors RT_USE_BVH; PACKED reads leaf triangles from the Morton-ordered
 // float4 x 3 array (leaf i holds sorted triangles 2i, 2i+1) instead of Indices -> Vertices.
-template <bool USE_BVH, bool PACKED>
+// STATS adds the traversal counters (box tests, triangle tests, hits, rays) to stats[0..3].
+template <bool USE_BVH, bool PACKED, bool STATS>
 __global__ __launch_bounds__(256) void k_trace(TraceParams p, const uint32_t* __restrict__ indices,
                                                const rt_vertex* __restrict__ verts, const rt_pbr_material* __restrict__ mats,
                                                const rt_texture_id* __restrict__ tex, const uint4* __restrict__ atlas,
                                                float4* __restrict__ rays, float4* __restrict__ old_rays,
                                                const uint32_t* __restrict__ ray_pixels, float4* __restrict__ scattered,
                                                float4* __restrict__ emitted, const float4* __restrict__ nodes,
-                                               const float4* __restrict__ sorted_tris) {
+                                               const float4* __restrict__ sorted_tris, unsigned long long* __restrict__ stats) {
     __shared__ uint32_t s_off[33];
     __shared__ uint32_t s_n[33];
     if (USE_BVH) {
@@ -244,15 +245,15 @@ __global__ __launch_bounds__(256) void k_trace(TraceParams p, const uint32_t* __
     Hit best;
     best.t = tmax_r; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
     uint32_t best_ci = 0u;
-    bool have_ci = false;
+    uint32_t n_nodes = 0u, n_tris = 0u;
 
     if (!USE_BVH) {
         // shader/CS_TraceRays.hlsl:160-175
         for (uint32_t ci = 0; ci < p.num_indices; ci += 3u) {
             Hit h = intersect_tri(org, dir, vpos(verts, indices[ci]), vpos(verts, indices[ci + 1]), vpos(verts, indices[ci + 2]));
             check_hit(h, tmin_r, tmax_r, ci, best, best_ci);
+            if (STATS) n_tris++;
         }
-        have_ci = true;
     } else {
         // shader/CS_TraceRays.hlsl:179-237, walked without a stack (see the file header)
         const f3 inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(256) void k_trace(TraceParams p, const uint32_t* __
         for (;;) {
             const float4 lo = nodes[2 * (size_t)node], hi = nodes[2 * (size_t)node + 1];
             const float bt = slab(org, inv_d, tmin_r, tmax_r, lo, hi);
+            if (STATS) n_nodes++;
             // the trunk is entered on any box hit; every other node also needs to start before the best hit
             bool enter = (bt != 1e30f) && (first || bt < best.t);
             first = false;
@@ -283,6 +285,7 @@ __global__ __launch_bounds__(256) void k_trace(TraceParams p, const uint32_t* __
                     a = vpos(verts, indices[ci0]); b = vpos(verts, indices[ci0 + 1]); c = vpos(verts, indices[ci0 + 2]);
                 }
                 check_hit(intersect_tri(org, dir, a, b, c), tmin_r, tmax_r, ci0, best, best_ci);
+                if (STATS) n_tris += (l1 != 0xffffffffu) ? 2u : 1u;
                 if (l1 != 0xffffffffu) {
                     const uint32_t ci1 = l1 & 0x7fffffffu;
                     if (PACKED) {
@@ -305,9 +308,22 @@ __global__ __launch_bounds__(256) void k_trace(TraceParams p, const uint32_t* __
             }
             if (done) break;
         }
-        have_ci = true;
     }
-    (void)have_ci;
+    if (STATS) {
+        unsigned long long c0 = n_nodes, c1 = n_tris, c2 = (best.t != tmax_r) ? 1u : 0u, c3 = 1u;
+        if (__builtin_amdgcn_ballot_w64(true) == ~0ull) {
+            // whole wave present: one atomic per counter per wave
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                c0 += __shfl_xor(c0, d, 64); c1 += __shfl_xor(c1, d, 64); c2 += __shfl_xor(c2, d, 64); c3 += __shfl_xor(c3, d, 64);
+            }
+            if ((threadIdx.x & 63u) == 0u) {
+                atomicAdd(&stats[0], c0); atomicAdd(&stats[1], c1); atomicAdd(&stats[2], c2); atomicAdd(&stats[3], c3);
+            }
+        } else {
+            atomicAdd(&stats[0], c0); atomicAdd(&stats[1], c1); atomicAdd(&stats[2], c2); atomicAdd(&stats[3], c3);
+        }
+    }
 
     // shader/CS_TraceRays.hlsl:116-126, 241-246
     const uint32_t pv = ray_pixels[tid];
@@ -431,6 +447,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
                  const rt_buffer* texture_atlas, uint32_t atlas_elements, rt_buffer* rays, rt_buffer* old_rays,
                  const rt_buffer* ray_pixels, rt_buffer* scattered_light, rt_buffer* emitted_light, const rt_buffer* bvh,
                  uint32_t first_ray) {
+    unsigned long long* stats = dev ? dev->trace_stats : nullptr;
     if (!dev || !info || !indices || !vertices || !materials || !texture_ids || !texture_atlas || !rays || !old_rays ||
         !ray_pixels || !scattered_light || !emitted_light)
         return RT_ERR_INVALID_ARGUMENT;
@@ -465,12 +482,13 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     p, (const uint32_t*)indices->ptr, (const rt_vertex*)vertices->ptr, (const rt_pbr_material*)materials->ptr,            \
         (const rt_texture_id*)texture_ids->ptr, (const uint4*)texture_atlas->ptr, (float4*)rays->ptr, (float4*)old_rays->ptr, \
         (const uint32_t*)ray_pixels->ptr, (float4*)scattered_light->ptr, (float4*)emitted_light->ptr, nodes
-    if (!use_bvh)
-        hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, dev->stream, RT_TRACE_ARGS, (const float4*)nullptr);
-    else if (accel)
-        hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, dev->stream, RT_TRACE_ARGS, (const float4*)accel->sorted_tris);
-    else
-        hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, dev->stream, RT_TRACE_ARGS, (const float4*)nullptr);
+    const float4* st = accel ? (const float4*)accel->sorted_tris : nullptr;
+    if (!use_bvh && !stats) hipLaunchKernelGGL((k_trace<false, false, false>), grid, block, 0, dev->stream, RT_TRACE_ARGS, st, stats);
+    else if (!use_bvh) hipLaunchKernelGGL((k_trace<false, false, true>), grid, block, 0, dev->stream, RT_TRACE_ARGS, st, stats);
+    else if (accel && !stats) hipLaunchKernelGGL((k_trace<true, true, false>), grid, block, 0, dev->stream, RT_TRACE_ARGS, st, stats);
+    else if (accel) hipLaunchKernelGGL((k_trace<true, true, true>), grid, block, 0, dev->stream, RT_TRACE_ARGS, st, stats);
+    else if (!stats) hipLaunchKernelGGL((k_trace<true, false, false>), grid, block, 0, dev->stream, RT_TRACE_ARGS, st, stats);
+    else hipLaunchKernelGGL((k_trace<true, false, true>), grid, block, 0, dev->stream, RT_TRACE_ARGS, st, stats);
 #undef RT_TRACE_ARGS
     return rt_launch_status();
 }
@@ -478,6 +496,12 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
 }  // namespace
 
 extern "C" {
+
+int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats) {
+    if (!dev || (stats && stats->bytes < 32u)) return RT_ERR_INVALID_ARGUMENT;
+    dev->trace_stats = stats ? (unsigned long long*)stats->ptr : nullptr;
+    return RT_OK;
+}
 
 int rt_camera_ray_generation(rt_device* dev, const rt_camera_ray_gen_info* info, rt_buffer* rays, rt_buffer* old_rays,
                              rt_buffer* ray_pixels, uint32_t first_row, uint32_t num_rows) {

@@ -18,7 +18,7 @@ from .runtime import Accel, Device
 class Pipeline:
     def __init__(self, dev, scene, width, height, inverse_view, inverse_projection, rpp=1, depth=3, aa=1.5, dof=0.0,
                  use_bvh=True, use_accel=True, raygen_seeds=None, trace_seeds=None, first_row=0, num_rows=None,
-                 rebuild_every_cycle=False):
+                 rebuild_every_cycle=False, output_ptr=None):
         self.dev = dev
         self.lib = dev.lib
         self.width, self.height, self.rpp, self.depth = int(width), int(height), int(rpp), int(depth)
@@ -51,7 +51,8 @@ class Pipeline:
         self.emitted = dev.alloc(16 * nr)
         npx = max(self.num_rows * self.width, 1)
         self.result = dev.alloc(16 * npx)
-        self.output = dev.alloc(16 * npx)
+        # the tone-mapped band may live in caller memory (e.g. a torch tensor that a collective will read)
+        self.output = dev.wrap(output_ptr, 16 * npx) if output_ptr else dev.alloc(16 * npx)
 
         self.bvh = None
         self.accel = None

@@ -74,6 +74,11 @@ int rt_device_set_stream(rt_device* dev, void* hip_stream); /* adopt a caller-ow
 int rt_device_index(rt_device* dev);
 const char* rt_error_string(int code);
 
+/* Instrumentation (no counterpart in the reference): while a 32-byte buffer is set, every trace launch adds
+ * {box tests, triangle tests, rays that hit, rays} as four uint64 to it (a slower kernel variant); NULL turns
+ * it off. The counts fix the algorithmic bytes per ray of a workload. */
+int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats);
+
 int rt_event_create(rt_device* dev, rt_event** out);
 int rt_event_record(rt_event* ev);                       /* on the device's stream */
 int rt_event_elapsed_ms(rt_event* start, rt_event* stop, float* ms); /* synchronises on stop */

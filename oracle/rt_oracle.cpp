@@ -10,7 +10,7 @@
 // so that every float expression rounds once per written operation.
 //
 // HLSL -> C++ rules used throughout:
-//   saturate(NaN) = 0; min/max = fminf/fmaxf (IEEE minNum/maxNum); round = rintf
+//   saturate(NaN) = 0; min/max = IEEE minNum/maxNum with -0 < +0 (hmin/hmax below); round = rintf
 //   (ties to even); float->uint truncates, negatives and NaN give 0, overflow
 //   saturates; rcp(x) = 1.0f/x; normalize(v) = v / sqrt(dot(v,v)); length = sqrt(dot);
 //   dot(a,b) = ((a.x*b.x + a.y*b.y) + a.z*b.z); lerp(a,b,t) = a + t*(b-a);
@@ -43,9 +43,23 @@ inline f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
 inline float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 inline f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 inline f3 normalize(f3 a) { return a / sqrtf(dot(a, a)); }
-inline f3 vmin(f3 a, f3 b) { return mk(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
-inline f3 vmax(f3 a, f3 b) { return mk(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
-inline float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }   // NaN -> 0
+// HLSL min/max: the non-NaN operand if one is NaN, and -0 orders below +0 (what AMD's v_min_f32 /
+// v_max_f32 return; libm's fminf/fmaxf leave the zero case open)
+inline float hmin(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return std::signbit(a) ? a : b;
+    return a < b ? a : b;
+}
+inline float hmax(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return std::signbit(a) ? b : a;
+    return a > b ? a : b;
+}
+inline f3 vmin(f3 a, f3 b) { return mk(hmin(a.x, b.x), hmin(a.y, b.y), hmin(a.z, b.z)); }
+inline f3 vmax(f3 a, f3 b) { return mk(hmax(a.x, b.x), hmax(a.y, b.y), hmax(a.z, b.z)); }
+inline float saturate(float x) { return hmin(hmax(x, 0.0f), 1.0f); }   // NaN -> 0
 inline f3 saturate(f3 a) { return mk(saturate(a.x), saturate(a.y), saturate(a.z)); }
 inline float pow5(float x) { float x2 = x * x; return (x2 * x2) * x; }
 inline uint32_t f2u(float x) {
@@ -115,8 +129,8 @@ inline float intersect_aabb(const orc_ray& r, const orc_aabb& b, bool true_div, 
     if (true_div) { t1 = (bmin - o) / d; t2 = (bmax - o) / d; }
     else { t1 = (bmin - o) * inv_d; t2 = (bmax - o) * inv_d; }
     f3 lo = vmin(t1, t2), hi = vmax(t1, t2);
-    float tmin = fmaxf(lo.x, fmaxf(lo.y, lo.z));
-    float tmax = fminf(hi.x, fminf(hi.y, hi.z));
+    float tmin = hmax(lo.x, hmax(lo.y, lo.z));
+    float tmax = hmin(hi.x, hmin(hi.y, hi.z));
     if ((tmax < tmin) || (tmax <= 0.0f) || (tmax < r.tmin) || (tmin > r.tmax)) tmin = 1e30f;
     return tmin;
 }
@@ -312,9 +326,9 @@ void trace_one(uint32_t tid, const orc_trace_info* info, int use_bvh, bool true_
         f3 Fd = refracted_color(rough, metal, albedo, ndl, ndv, vdh, ldv);
         f3 Sc = mk(S.x, S.y, S.z), Em = mk(E.x, E.y, E.z);
         f3 k = (Fr + Fd) * ndl;
-        f3 newS = Sc * mk(fmaxf(0.0f, k.x), fmaxf(0.0f, k.y), fmaxf(0.0f, k.z));
+        f3 newS = Sc * mk(hmax(0.0f, k.x), hmax(0.0f, k.y), hmax(0.0f, k.z));
         f3 se = Sc * emis;
-        f3 newE = mk(fmaxf(0.0f, se.x), fmaxf(0.0f, se.y), fmaxf(0.0f, se.z)) + Em;
+        f3 newE = mk(hmax(0.0f, se.x), hmax(0.0f, se.y), hmax(0.0f, se.z)) + Em;
         S.x = newS.x; S.y = newS.y; S.z = newS.z;
         E.x = newE.x; E.y = newE.y; E.z = newE.z;
 
@@ -532,7 +546,7 @@ void orc_bvh_build(const orc_bvh_info* info, orc_aabb* bvh) {
         orc_aabb a = bvh[i1], b = a;
         if ((i2 - info->previous_index) < info->num_children) b = bvh[i2];
         else i2 = 0xffffffffu;
-        for (int k = 0; k < 3; k++) { a.mn[k] = fminf(a.mn[k], b.mn[k]); a.mx[k] = fmaxf(a.mx[k], b.mx[k]); }
+        for (int k = 0; k < 3; k++) { a.mn[k] = hmin(a.mn[k], b.mn[k]); a.mx[k] = hmax(a.mx[k], b.mx[k]); }
         a.link[0] = i1;
         a.link[1] = i2;
         bvh[info->current_index + t] = a;
