@@ -291,7 +291,7 @@ __device__ __forceinline__ void store_node(rt_aabb* nodes, uint32_t idx, const B
 // LDS slot order (slot s <-> node blockIdx.x*256 + s of level k0). Same arithmetic as
 // shader/CS_BVHBuild.hlsl:28-47: min/max union, links (first child, second child or 0xffffffff).
 __device__ __forceinline__ void upsweep_block(Box mine, uint32_t k0, const rt_levels& lv, rt_aabb* __restrict__ nodes,
-                                              float (*s_box)[6]) {
+                                              rt_aabb* __restrict__ anodes, float (*s_box)[6]) {
     const uint32_t tid = threadIdx.x;
     uint32_t cnt = 256u;
     uint32_t k = k0;
@@ -316,6 +316,7 @@ __device__ __forceinline__ void upsweep_block(Box mine, uint32_t k0, const rt_le
             }
             const uint32_t l0 = lv.off[k - 1] + c0;
             store_node(nodes, lv.off[k] + gi, mine, l0, has2 ? l0 + 1u : 0xffffffffu);
+            if (anodes) store_node(anodes, lv.aoff[k] + gi, mine, l0, has2 ? l0 + 1u : 0xffffffffu);
         }
     }
 }
@@ -327,7 +328,7 @@ template <bool PACKED, bool FUSED>
 __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv, const uint32_t* __restrict__ sorted,
                                                 const uint32_t* __restrict__ indices, const rt_vertex* __restrict__ verts,
                                                 const float4* __restrict__ tris, float4* __restrict__ sorted_tris,
-                                                rt_aabb* __restrict__ nodes) {
+                                                rt_aabb* __restrict__ nodes, rt_aabb* __restrict__ anodes) {
     __shared__ float s_box[256][6];
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t leaves = (num_prims + 1u) / 2u;
@@ -358,12 +359,14 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
             b.mx[0] = fmaxf(b.mx[0], px); b.mx[1] = fmaxf(b.mx[1], py); b.mx[2] = fmaxf(b.mx[2], pz);
         }
         store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
+        if (PACKED && anodes) store_node(anodes, lv.aoff[0] + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
     }
-    if (FUSED) upsweep_block(b, 0u, lv, nodes, s_box);
+    if (FUSED) upsweep_block(b, 0u, lv, nodes, anodes, s_box);
 }
 
 // continues the up-sweep from level k0 (already in memory), eight levels per launch
-__global__ __launch_bounds__(256) void k_upsweep(uint32_t k0, rt_levels lv, rt_aabb* __restrict__ nodes) {
+__global__ __launch_bounds__(256) void k_upsweep(uint32_t k0, rt_levels lv, rt_aabb* __restrict__ nodes,
+                                                 rt_aabb* __restrict__ anodes) {
     __shared__ float s_box[256][6];
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     Box b;
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256) void k_upsweep(uint32_t k0, rt_levels lv, rt_a
         float4 lo = p[0], hi = p[1];
         b.mn[0] = lo.x; b.mn[1] = lo.y; b.mn[2] = lo.z; b.mx[0] = lo.w; b.mx[1] = hi.x; b.mx[2] = hi.y;
     }
-    upsweep_block(b, k0, lv, nodes, s_box);
+    upsweep_block(b, k0, lv, nodes, anodes, s_box);
 }
 
 // one level, reference parameters (shader/CS_BVHBuild.hlsl:25-48)
@@ -497,7 +500,7 @@ int rt_bvh_build_leaves(rt_device* dev, const rt_bvh_info* info, const rt_buffer
     lv.count = 0;
     hipLaunchKernelGGL((k_leaves<false, false>), dim3(div_up(leaves, 256u)), dim3(256), 0, dev->stream, n, lv,
                        (const uint32_t*)morton_codes->ptr, (const uint32_t*)indices->ptr, (const rt_vertex*)vertices->ptr,
-                       (const float4*)nullptr, (float4*)nullptr, (rt_aabb*)bvh->ptr);
+                       (const float4*)nullptr, (float4*)nullptr, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr);
     return rt_launch_status();
 }
 
@@ -529,11 +532,18 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
     a->num_prims = 0;
     a->tris = a->sorted_tris = nullptr;
     a->keys_a = a->keys_b = nullptr;
+    a->anodes = nullptr;
     const size_t tri_bytes = (size_t)max_primitives * 48u, key_bytes = (size_t)max_primitives * 8u;
     hipError_t e = hipMalloc((void**)&a->tris, tri_bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&a->sorted_tris, tri_bytes + 48u);   // odd counts pad the last leaf
     if (e == hipSuccess) e = hipMalloc((void**)&a->keys_a, key_bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&a->keys_b, key_bytes);
+    {
+        rt_levels lv;
+        rt_make_levels(max_primitives, &lv);
+        // a smaller scene packed later never needs more slots than the largest one
+        if (e == hipSuccess) e = hipMalloc((void**)&a->anodes, (rt_aligned_node_slots(&lv) + 64u) * sizeof(rt_aabb));
+    }
     if (e != hipSuccess) {
         rt_accel_destroy(a);
         return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
@@ -550,6 +560,7 @@ int rt_accel_destroy(rt_accel* a) {
     if (a->sorted_tris) (void)hipFree(a->sorted_tris);
     if (a->keys_a) (void)hipFree(a->keys_a);
     if (a->keys_b) (void)hipFree(a->keys_b);
+    if (a->anodes) (void)hipFree(a->anodes);
     delete a;
     return RT_OK;
 }
@@ -596,9 +607,9 @@ int rt_accel_build(rt_accel* a, const float scene_min[3], const float scene_max[
     // four passes: the sorted pairs are back in keys_a (= src)
     const uint32_t leaves = lv.n[0];
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)src,
-                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr);
+                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, a->anodes);
     for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
-        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr);
+        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, a->anodes);
     if (morton_codes)
         hipLaunchKernelGGL(k_expand_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, n, src, (uint4*)morton_codes->ptr);
     return rt_launch_status();

@@ -24,6 +24,10 @@ int rt_device_create(int gpu_index, rt_device** out) {
     d->sort_table_words = 0;
     d->sort_totals = nullptr;
     d->trace_stats = nullptr;
+    d->hit_records = nullptr;
+    d->hit_ci = nullptr;
+    d->hit_capacity = 0;
+    d->queue_counter = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete d; return RT_ERR_HIP_BASE + (int)e; }
     e = hipMalloc((void**)&d->sort_totals, 512 * sizeof(uint32_t));
@@ -39,6 +43,9 @@ int rt_device_destroy(rt_device* dev) {
     (void)hipStreamSynchronize(dev->stream);
     if (dev->sort_table) (void)hipFree(dev->sort_table);
     if (dev->sort_totals) (void)hipFree(dev->sort_totals);
+    if (dev->hit_records) (void)hipFree(dev->hit_records);
+    if (dev->hit_ci) (void)hipFree(dev->hit_ci);
+    if (dev->queue_counter) (void)hipFree(dev->queue_counter);
     if (dev->owns_stream && dev->stream) (void)hipStreamDestroy(dev->stream);
     delete dev;
     return RT_OK;

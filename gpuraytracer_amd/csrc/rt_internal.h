@@ -16,6 +16,11 @@ struct rt_device {
     size_t sort_table_words;
     uint32_t* sort_totals;     // [256] digit totals + [256] exclusive digit bases
     unsigned long long* trace_stats;   // optional traversal counters (rt_device_set_trace_stats)
+    // workspace of the wavefront trace: closest-hit records between the traversal and shading kernels
+    float4* hit_records;       // [hit_capacity] (t, u, v, facing)
+    uint32_t* hit_ci;          // [hit_capacity] first index slot of the hit triangle
+    size_t hit_capacity;
+    uint32_t* queue_counter;   // ray queue head of the persistent traversal kernel (256 bytes)
 };
 
 struct rt_buffer {
@@ -36,6 +41,7 @@ struct rt_accel {
     uint32_t num_prims;        // set by rt_accel_pack
     float4* tris;              // [3*max_prims] packed positions, original order
     float4* sorted_tris;       // [3*max_prims] packed positions, Morton order (w of vertex 0 = 3*tri)
+    rt_aabb* anodes;           // pair-aligned private copy of the hierarchy (rt_levels::aoff placement)
     uint2* keys_a;             // [max_prims] (code, 3*tri)
     uint2* keys_b;             // [max_prims]
 };
@@ -67,24 +73,36 @@ int rt_sort_workspace(rt_device* dev, uint32_t num_elements);   // grows dev->so
 // level schedule of the balanced hierarchy (src/RaytracerPipeline.cpp:465-467, 497-559):
 // level 0 = leaves at node 1; level k has ceil(n_{k-1} / 2) nodes appended after level k-1;
 // the level holding a single node is the root and is stored at node 0.
+//
+// aoff is a second, private placement of the same nodes used by the accel's own copy: every level starts at
+// an even slot, so the sibling pair (2j, 2j+1) of any level shares one 64-byte line.
 struct rt_levels {
     uint32_t count;            // number of levels including the root level
     uint32_t n[33];            // nodes per level
     uint32_t off[33];          // first node index of each level (root level: 0)
+    uint32_t aoff[33];         // first slot of each level in the pair-aligned copy (root level: 0)
 };
 static inline bool rt_make_levels(uint32_t num_prims, rt_levels* lv) {
     if (num_prims < 3u) return false;
-    uint32_t n = (num_prims + 1u) / 2u, off = 1u, k = 0;
+    uint32_t n = (num_prims + 1u) / 2u, off = 1u, aoff = 2u, k = 0;
     for (;;) {
         lv->n[k] = n;
         lv->off[k] = (n == 1u) ? 0u : off;
+        lv->aoff[k] = (n == 1u) ? 0u : aoff;
         k++;
         if (n == 1u) break;
         off += n;
+        aoff += (n + 1u) & ~1u;
         n = (n + 1u) / 2u;
     }
     lv->count = k;
     return true;
+}
+// slots the pair-aligned copy needs
+static inline size_t rt_aligned_node_slots(const rt_levels* lv) {
+    size_t slots = 2;
+    for (uint32_t k = 0; k + 1u < lv->count; k++) slots += (lv->n[k] + 1u) & ~1u;
+    return slots;
 }
 
 #endif

@@ -1,0 +1,647 @@
+// BVH traversal + per-ray shading for gfx950.
+//
+// Semantics follow the reference's shader/CS_TraceRays.hlsl, PerRayShading.hlsli and Random.hlsli
+// (dispatched by src/RaytracerPipeline.cpp:687-729), including their quirks: a missed ray is left
+// untouched, the interpolated normal is not renormalised, texture offsets are byte counts used as
+// texel indices, the seed of a ray is a function of its global index.
+//
+// What is new is how the work is laid out:
+//  * The reference keeps a 48-entry stack of node indices in private memory. The hierarchy it builds
+//    is a balanced implicit tree whose shape depends only on the primitive count (children of node i
+//    of level k are nodes 2i, 2i+1 of level k-1), so the same left-first depth-first order is walked
+//    here with two registers (level, index) and no stack: "pop" = climb past every right child (the
+//    trailing one bits of the index) and every only child, then step to the sibling. The order of box
+//    and triangle tests, hence the closest hit and its tie-breaking, is exactly the reference's.
+//  * The reference runs one thread per ray through traversal and shading. Here traversal is a
+//    persistent kernel: waves pull ray indices from an atomic queue (one aggregated atomic per wave
+//    refill) and refill finished lanes, so a wave never idles behind its longest ray; a lane that
+//    reaches a leaf parks until enough lanes of its wave are parked, so the expensive triangle tests
+//    run with many lanes active; closest hits go to a 20-byte record and a second, fully
+//    convergent kernel shades them.
+//
+// Arithmetic conventions are those of rt_math.h; the slab test multiplies by one IEEE reciprocal of
+// each direction component per ray instead of dividing per box.
+
+#include <cstdlib>
+#include <cstring>
+
+#include "rt_internal.h"
+#include "rt_math.h"
+
+namespace {
+
+using namespace rtm;
+
+struct TraceParams {
+    int32_t width;
+    uint32_t num_indices, num_rays, rpp;
+    uint32_t seed[3];
+    uint32_t first_ray;
+    uint32_t atlas_elems;
+    uint32_t num_prims;
+    uint32_t num_materials, num_textures;
+    uint32_t leaf_threshold;
+    uint32_t queue_chunk;      // rays per queue of the persistent traversal kernel (a multiple of 64)
+    rt_levels lv;
+};
+
+struct Hit { float t, u, v, w; };
+
+// shader/CS_TraceRays.hlsl:46-77
+__device__ __forceinline__ Hit intersect_tri(f3 o, f3 d, f3 v1, f3 v2, f3 v3) {
+    f3 e1 = sub(v2, v1), e2 = sub(v3, v1), tv = sub(o, v1);
+    f3 pv = cross3(d, e2), qv = cross3(tv, e1);
+    float det = dot3(e1, pv);
+    float inv = (fabsf(det) < 1e-6f) ? 0.0f : 1.0f / det;
+    float cw = rintf(fabsf(det) * inv);
+    float t = dot3(e2, qv) * inv, u = dot3(tv, pv) * inv, v = dot3(d, qv) * inv;
+    Hit h;
+    if (t < 1e-6f || u < 0.0f || v < 0.0f || u + v > 1.0f) { h.t = -1.0f; h.u = -1.0f; h.v = -1.0f; }
+    else { h.t = t; h.u = u; h.v = v; }
+    h.w = cw;
+    return h;
+}
+
+// shader/CS_TraceRays.hlsl:100-113 (the accepted hit remembers the triangle's first index slot)
+__device__ __forceinline__ void check_hit(const Hit& h, float tmin, float tmax, uint32_t ci, Hit& best, uint32_t& best_ci) {
+    bool use = (tmin <= h.t) && (tmax > h.t) && (h.t < best.t);
+    if (use) { best = h; best_ci = ci; }
+}
+
+// shader/CS_TraceRays.hlsl:81-97
+__device__ __forceinline__ float slab(f3 o, f3 inv_d, float tmin_r, float tmax_r, float4 lo, float4 hi) {
+    f3 t1 = mul(sub(mk(lo.x, lo.y, lo.z), o), inv_d);
+    f3 t2 = mul(sub(mk(lo.w, hi.x, hi.y), o), inv_d);
+    float tmin = fmaxf(fminf(t1.x, t2.x), fmaxf(fminf(t1.y, t2.y), fminf(t1.z, t2.z)));
+    float tmax = fminf(fmaxf(t1.x, t2.x), fminf(fmaxf(t1.y, t2.y), fmaxf(t1.z, t2.z)));
+    if ((tmax < tmin) || (tmax <= 0.0f) || (tmax < tmin_r) || (tmin > tmax_r)) tmin = 1e30f;
+    return tmin;
+}
+
+// shader/PerRayShading.hlsli:60-74. A texture id past the table reads zeros, like an out-of-range
+// structured-buffer load.
+__device__ __forceinline__ f3 sample_texture(const rt_texture_id* __restrict__ tex, uint32_t num_textures, uint32_t tid, float u,
+                                             float v, const uint4* __restrict__ atlas, uint32_t atlas_elems) {
+    rt_texture_id id;
+    id.offset = 0u; id.width = 0u; id.height = 0u; id.row_pitch = 0u;
+    if (tid < num_textures) id = tex[tid];
+    uint32_t sx = f2u(rintf(u * (float)(id.width - 1u)));
+    uint32_t sy = f2u(rintf(v * (float)(id.height - 1u)));
+    uint32_t loc = sx + id.row_pitch * sy + id.offset;
+    uint32_t e = loc >> 1;
+    uint2 px = make_uint2(0u, 0u);                      // loads past the atlas return 0
+    if (e < atlas_elems) px = reinterpret_cast<const uint2*>(atlas)[loc];
+    f3 c = mk((float)(px.x & 0xffffu), (float)(px.x >> 16), (float)(px.y & 0xffffu));
+    c = scale(c, 1.5259022e-5f);
+    return mul(c, c);
+}
+
+// shader/PerRayShading.hlsli:79-106
+__device__ __forceinline__ f3 reflected_color(float rough, f3 f0, float ndl, float ndv, float ndh, float vdh) {
+    float alpha = rough * rough;
+    float sf = pow5(saturatef(1.0f - vdh));
+    f3 F = mk((f0.x + sf) - f0.x * sf, (f0.y + sf) - f0.y * sf, (f0.z + sf) - f0.z * sf);
+    float a2 = alpha * alpha;
+    float ndh2 = ndh * ndh;
+    float sq = (ndh2 * a2 - ndh2) + 1.0f;
+    float dden = (3.141592654f * sq) * sq;
+    float k = alpha * 0.5f;
+    float gx = (ndv - k * ndv) + k;
+    float gy = (ndl - k * ndl) + k;
+    float den = dden * (gx * gy) + 1e-6f;
+    return mk(((0.25f * F.x) * a2) / den, ((0.25f * F.y) * a2) / den, ((0.25f * F.z) * a2) / den);
+}
+
+// shader/PerRayShading.hlsli:110-133
+__device__ __forceinline__ f3 refracted_color(float rough, float metal, f3 albedo, float ndl, float ndv, float vdh, float ldv) {
+    float facing = ldv * 0.5f + 0.5f;
+    float prough = facing * (0.9f - 0.4f * facing);
+    float rgh = prough * (vdh / ((ndl + ndv) + 1e-6f)) + prough;
+    float smooth = (1.05f * (1.0f - pow5(1.0f - ndl))) * (1.0f - pow5(1.0f - ndv));
+    float alpha = rough * rough;
+    float single = (smooth + alpha * (rgh - smooth)) / 3.141592654f;
+    float multi = 0.1159f * alpha;
+    f3 diff = mk(albedo.x * (albedo.x * multi + single), albedo.y * (albedo.y * multi + single),
+                 albedo.z * (albedo.z * multi + single));
+    return mk(diff.x - diff.x * metal, diff.y - diff.y * metal, diff.z - diff.z * metal);
+}
+
+// shader/CS_TraceRays.hlsl:129-144
+__device__ __forceinline__ float interp(float a1, float a2, float a3, float u, float v) {
+    return (a1 * ((1.0f - u) - v) + a2 * u) + a3 * v;
+}
+
+__device__ __forceinline__ f3 vpos(const rt_vertex* __restrict__ verts, uint32_t i) {
+    const float* p = verts[i].position;
+    return mk(p[0], p[1], p[2]);
+}
+
+struct ShadeBuffers {
+    const uint32_t* indices;
+    const rt_vertex* verts;
+    const rt_pbr_material* mats;
+    const rt_texture_id* tex;
+    const uint4* atlas;
+    float4* rays;
+    float4* old_rays;
+    const uint32_t* ray_pixels;
+    float4* scattered;
+    float4* emitted;
+};
+
+// Everything CS_TraceRays does after the closest hit is known (shader/CS_TraceRays.hlsl:241-292): light
+// buffers, shading, the scattered ray. tid is the ray's index in this device's buffers.
+__device__ __forceinline__ void shade_ray(const TraceParams& p, const ShadeBuffers& b, uint32_t tid, float4 r0, float4 r1,
+                                          const Hit& best, uint32_t best_ci) {
+    const float4 o0 = b.old_rays[2 * (size_t)tid], o1 = b.old_rays[2 * (size_t)tid + 1];
+    const f3 org = mk(r0.x, r0.y, r0.z), dir = mk(r0.w, r1.x, r1.y);
+    const float tmin_r = r1.z, tmax_r = r1.w;
+
+    // shader/CS_TraceRays.hlsl:116-126, 241-246
+    const uint32_t pv = b.ray_pixels[tid];
+    const uint32_t px = pv >> 16, py = pv & 0xffffu;
+    const uint32_t off = __float_as_uint(o1.w);
+    const uint32_t idx = ((uint32_t)p.width * py + px) * p.rpp + off - p.first_ray;
+    float4 S = b.scattered[idx];
+    float4 E = b.emitted[idx];
+
+    if (best.t != tmax_r) {
+        const uint32_t ia = b.indices[best_ci], ib = b.indices[best_ci + 1], ic = b.indices[best_ci + 2];
+        const rt_vertex A = b.verts[ia], B = b.verts[ib], C = b.verts[ic];
+        const uint32_t gid = tid + p.first_ray;
+        uint32_t s0 = gid * (gid + 17u);
+        xorshift(s0);
+        uint32_t sx = s0 + p.seed[0], sy = s0 + p.seed[1];
+
+        const float u = best.u, v = best.v;
+        const float tu = interp(A.uv[0], B.uv[0], C.uv[0], u, v), tv = interp(A.uv[1], B.uv[1], C.uv[1], u, v);
+        const f3 N = mk(interp(A.normal[0], B.normal[0], C.normal[0], u, v), interp(A.normal[1], B.normal[1], C.normal[1], u, v),
+                        interp(A.normal[2], B.normal[2], C.normal[2], u, v));
+
+        // shader/Random.hlsli:100-126
+        f3 p1 = normalize3(mk(-N.z, 0.0f, N.x));
+        if (N.z == 0.0f && N.x == 0.0f) p1 = mk(1.0f, 0.0f, 0.0f);
+        const f3 p2 = normalize3(cross3(N, p1));
+        p1 = normalize3(cross3(N, p2));
+        const float rn1 = rnd(sx), rn2 = rnd(sy);
+        const float hy = sqrtf(1.0f - rn2);
+        const float hr = sqrtf(rn2);
+        const float phi = 6.2831853f * rn1;
+        float sn, cs;
+        sincos_poly(phi, &sn, &cs);
+        const f3 L = add(add(scale(p1, cs * hr), scale(N, hy)), scale(p2, sn * hr));
+
+        if (dot3(mk(o0.w, o1.x, o1.y), mk(o0.w, o1.x, o1.y)) == 0.0f) {
+            S.x = 1.0f; S.y = 1.0f; S.z = 1.0f;
+            E.x = 0.0f; E.y = 0.0f; E.z = 0.0f;
+        }
+
+        // shader/PerRayShading.hlsli:138-191. A material id past the table reads zeros.
+        const f3 V = mk(-dir.x, -dir.y, -dir.z);
+        const f3 H = normalize3(add(V, L));
+        rt_pbr_material m;
+        if (A.material_id < p.num_materials) m = b.mats[A.material_id];
+        else {
+            m.albedo[0] = m.albedo[1] = m.albedo[2] = m.roughness = m.f0_color[0] = m.f0_color[1] = m.f0_color[2] = 0.0f;
+            m.metallic = m.emissive[0] = m.emissive[1] = m.emissive[2] = 0.0f;
+            m.albedo_texture = m.roughness_texture = m.f0_texture = m.metallic_texture = m.emissive_texture = 0u;
+        }
+        const f3 ta = sample_texture(b.tex, p.num_textures, m.albedo_texture, tu, tv, b.atlas, p.atlas_elems);
+        const f3 tr = sample_texture(b.tex, p.num_textures, m.roughness_texture, tu, tv, b.atlas, p.atlas_elems);
+        const f3 tf = sample_texture(b.tex, p.num_textures, m.f0_texture, tu, tv, b.atlas, p.atlas_elems);
+        const f3 tm = sample_texture(b.tex, p.num_textures, m.metallic_texture, tu, tv, b.atlas, p.atlas_elems);
+        const f3 te = sample_texture(b.tex, p.num_textures, m.emissive_texture, tu, tv, b.atlas, p.atlas_elems);
+        const f3 albedo = mul(mk(m.albedo[0], m.albedo[1], m.albedo[2]), ta);
+        const float rough = m.roughness * tr.x;
+        const f3 f0 = mul(mk(m.f0_color[0], m.f0_color[1], m.f0_color[2]), tf);
+        const float metal = m.metallic * tm.x;
+        const f3 emis = mul(mk(m.emissive[0], m.emissive[1], m.emissive[2]), te);
+
+        const float vdh = saturatef(dot3(V, H)), ndh = saturatef(dot3(N, H)), ndv = saturatef(dot3(N, V));
+        const float ndl = saturatef(dot3(N, L)), ldv = saturatef(dot3(L, V));
+        const f3 Fr = reflected_color(rough, f0, ndl, ndv, ndh, vdh);
+        const f3 Fd = refracted_color(rough, metal, albedo, ndl, ndv, vdh, ldv);
+        const f3 Sc = mk(S.x, S.y, S.z), Em = mk(E.x, E.y, E.z);
+        const f3 kk = scale(add(Fr, Fd), ndl);
+        const f3 newS = mul(Sc, mk(fmaxf(0.0f, kk.x), fmaxf(0.0f, kk.y), fmaxf(0.0f, kk.z)));
+        const f3 se = mul(Sc, emis);
+        const f3 newE = add(mk(fmaxf(0.0f, se.x), fmaxf(0.0f, se.y), fmaxf(0.0f, se.z)), Em);
+        S.x = newS.x; S.y = newS.y; S.z = newS.z;
+        E.x = newE.x; E.y = newE.y; E.z = newE.z;
+
+        // new ray from the hit point; the traced ray becomes the "old" ray, keeping the sample slot in TMax
+        b.rays[2 * (size_t)tid] = make_float4(org.x + dir.x * best.t, org.y + dir.y * best.t, org.z + dir.z * best.t, L.x);
+        b.rays[2 * (size_t)tid + 1] = make_float4(L.y, L.z, tmin_r, tmax_r);
+        b.old_rays[2 * (size_t)tid] = r0;
+        b.old_rays[2 * (size_t)tid + 1] = make_float4(r1.x, r1.y, r1.z, o1.w);
+    }
+    b.scattered[idx] = S;
+    b.emitted[idx] = E;
+}
+
+// sums four per-thread counters over the workgroup's present lanes into stats[0..3]
+__device__ __forceinline__ void add_stats(unsigned long long* stats, unsigned long long c0, unsigned long long c1,
+                                          unsigned long long c2, unsigned long long c3) {
+    if (__builtin_amdgcn_ballot_w64(true) == ~0ull) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            c0 += __shfl_xor(c0, d, 64); c1 += __shfl_xor(c1, d, 64); c2 += __shfl_xor(c2, d, 64); c3 += __shfl_xor(c3, d, 64);
+        }
+        if ((threadIdx.x & 63u) == 0u) {
+            atomicAdd(&stats[0], c0); atomicAdd(&stats[1], c1); atomicAdd(&stats[2], c2); atomicAdd(&stats[3], c3);
+        }
+    } else {
+        atomicAdd(&stats[0], c0); atomicAdd(&stats[1], c1); atomicAdd(&stats[2], c2); atomicAdd(&stats[3], c3);
+    }
+}
+
+// leaf triangles: PACKED reads the Morton-ordered float4 x 3 array (leaf i holds sorted triangles 2i, 2i+1),
+// otherwise Indices -> Vertices through the leaf's links
+template <bool PACKED>
+__device__ __forceinline__ void test_leaf(f3 org, f3 dir, float tmin_r, float tmax_r, uint32_t leaf, uint32_t l0, uint32_t l1,
+                                          const uint32_t* __restrict__ indices, const rt_vertex* __restrict__ verts,
+                                          const float4* __restrict__ sorted_tris, Hit& best, uint32_t& best_ci) {
+    const uint32_t ci0 = l0 & 0x7fffffffu;
+    f3 a, b, c;
+    if (PACKED) {
+        const float4* t = sorted_tris + 6 * (size_t)leaf;
+        float4 ta = t[0], tb = t[1], tc = t[2];
+        a = mk(ta.x, ta.y, ta.z); b = mk(tb.x, tb.y, tb.z); c = mk(tc.x, tc.y, tc.z);
+    } else {
+        a = vpos(verts, indices[ci0]); b = vpos(verts, indices[ci0 + 1]); c = vpos(verts, indices[ci0 + 2]);
+    }
+    check_hit(intersect_tri(org, dir, a, b, c), tmin_r, tmax_r, ci0, best, best_ci);
+    if (l1 != 0xffffffffu) {
+        const uint32_t ci1 = l1 & 0x7fffffffu;
+        if (PACKED) {
+            const float4* t = sorted_tris + 6 * (size_t)leaf + 3;
+            float4 ta = t[0], tb = t[1], tc = t[2];
+            a = mk(ta.x, ta.y, ta.z); b = mk(tb.x, tb.y, tb.z); c = mk(tc.x, tc.y, tc.z);
+        } else {
+            a = vpos(verts, indices[ci1]); b = vpos(verts, indices[ci1 + 1]); c = vpos(verts, indices[ci1 + 2]);
+        }
+        check_hit(intersect_tri(org, dir, a, b, c), tmin_r, tmax_r, ci1, best, best_ci);
+    }
+}
+
+// Left-first depth-first successor of node i of level k once its subtree is finished: climb past every
+// right child (the trailing one bits of i), then step to the sibling. The sibling of the last node of a
+// level with an odd node count does not exist; its index equals the level's node count and the walk
+// skips it without a box test (it is odd, so the next pop climbs on). Returns true when the walk is
+// back at the root level, i.e. the traversal is complete.
+__device__ __forceinline__ bool pop_node(uint32_t& k, uint32_t& i, uint32_t root_level) {
+    const uint32_t c = (uint32_t)__builtin_ctz(~i);
+    i = (i >> c) + 1u;
+    k += c;
+    return k >= root_level;
+}
+
+// ---- simple form: one thread per ray through traversal and shading (also the RT_USE_BVH = 0 path) ----
+template <bool USE_BVH, bool PACKED, bool STATS>
+__global__ __launch_bounds__(256) void k_trace(TraceParams p, ShadeBuffers b, const float4* __restrict__ nodes,
+                                               const float4* __restrict__ sorted_tris, unsigned long long* __restrict__ stats) {
+    __shared__ uint32_t s_off[33];
+    __shared__ uint32_t s_n[33];
+    if (USE_BVH) {
+        if (threadIdx.x < 33u) { s_off[threadIdx.x] = p.lv.off[threadIdx.x]; s_n[threadIdx.x] = p.lv.n[threadIdx.x]; }
+        __syncthreads();
+    }
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    if (tid >= p.num_rays) return;
+
+    const float4 r0 = b.rays[2 * (size_t)tid], r1 = b.rays[2 * (size_t)tid + 1];
+    const f3 org = mk(r0.x, r0.y, r0.z), dir = mk(r0.w, r1.x, r1.y);
+    const float tmin_r = r1.z, tmax_r = r1.w;
+    Hit best;
+    best.t = tmax_r; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
+    uint32_t best_ci = 0u;
+    uint32_t n_nodes = 0u, n_tris = 0u;
+
+    if (!USE_BVH) {
+        // shader/CS_TraceRays.hlsl:160-175
+        for (uint32_t ci = 0; ci < p.num_indices; ci += 3u) {
+            Hit h = intersect_tri(org, dir, vpos(b.verts, b.indices[ci]), vpos(b.verts, b.indices[ci + 1]), vpos(b.verts, b.indices[ci + 2]));
+            check_hit(h, tmin_r, tmax_r, ci, best, best_ci);
+            if (STATS) n_tris++;
+        }
+    } else {
+        // shader/CS_TraceRays.hlsl:179-237, walked without a stack
+        const f3 inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+        const uint32_t root_level = p.lv.count - 1u;
+        if (STATS) n_nodes++;
+        // the trunk is entered on any box hit; every other node also has to start before the best hit
+        if (slab(org, inv_d, tmin_r, tmax_r, nodes[0], nodes[1]) != 1e30f) {
+            uint32_t k = root_level - 1u, i = 0u;
+            for (;;) {
+                if (i < s_n[k]) {
+                    const size_t node = (size_t)s_off[k] + i;
+                    const float4 lo = nodes[2 * node], hi = nodes[2 * node + 1];
+                    const float bt = slab(org, inv_d, tmin_r, tmax_r, lo, hi);
+                    if (STATS) n_nodes++;
+                    const bool enter = (bt != 1e30f) && (bt < best.t);
+                    if (enter && k > 0u) { k--; i <<= 1; continue; }
+                    if (enter) {
+                        const uint32_t l0 = __float_as_uint(hi.z), l1 = __float_as_uint(hi.w);
+                        test_leaf<PACKED>(org, dir, tmin_r, tmax_r, i, l0, l1, b.indices, b.verts, sorted_tris, best, best_ci);
+                        if (STATS) n_tris += (l1 != 0xffffffffu) ? 2u : 1u;
+                    }
+                }
+                if (pop_node(k, i, root_level)) break;
+            }
+        }
+    }
+    if (STATS) add_stats(stats, n_nodes, n_tris, (best.t != tmax_r) ? 1u : 0u, 1u);
+    shade_ray(p, b, tid, r0, r1, best, best_ci);
+}
+
+// ---- wavefront form: persistent traversal kernel + convergent shading kernel ----
+
+constexpr uint32_t kNoRay = 0xffffffffu;
+
+template <bool PACKED, bool STATS>
+__global__ __launch_bounds__(256) void k_traverse(TraceParams p, const uint32_t* __restrict__ indices,
+                                                  const rt_vertex* __restrict__ verts, const float4* __restrict__ rays,
+                                                  const float4* __restrict__ nodes, const float4* __restrict__ sorted_tris,
+                                                  float4* __restrict__ hit_records, uint32_t* __restrict__ hit_ci,
+                                                  uint32_t* __restrict__ queue, unsigned long long* __restrict__ stats) {
+    __shared__ uint2 s_level[33];                  // (first node, node count) of every level
+    if (threadIdx.x < 33u) s_level[threadIdx.x] = make_uint2(p.lv.off[threadIdx.x], p.lv.n[threadIdx.x]);
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t root_level = p.lv.count - 1u;
+    const float4 root_lo = nodes[0], root_hi = nodes[1];
+
+    uint32_t ray = kNoRay;            // index of the ray this lane is walking
+    bool exhausted = false;           // the queue had no ray left for this lane
+    bool parked = false;              // waiting at a leaf for the wave's next triangle round
+    f3 org = mk(0.0f, 0.0f, 0.0f), dir = org, inv_d = org;
+    float tmin_r = 0.0f, tmax_r = 0.0f;
+    Hit best;
+    best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
+    uint32_t best_ci = 0u, k = 0u, i = 0u, l0 = 0u, l1 = 0u;
+    uint32_t n_nodes = 0u, n_tris = 0u, n_hits = 0u, n_rays = 0u;
+    uint32_t q = blockIdx.x & 7u, queues_tried = 0u;       // wave-uniform
+
+    for (;;) {
+        // 1. refill: every lane without a ray takes the next index; one atomic per wave.
+        //    Eight queues, each over a contiguous eighth of the rays. Workgroups b and b + 8 are dealt to the same
+        //    XCD, so the waves that share an L2 start on the same queue, i.e. on the same image region; a wave
+        //    whose queue has run dry moves on to the next one (a speed choice only: any wave may take any ray).
+        const bool need = (ray == kNoRay) && !exhausted;
+        const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(need);
+        if (need_mask) {
+            if (queues_tried >= 8u) {
+                exhausted = exhausted || need;             // every queue has been seen empty
+            } else {
+                const uint32_t q_begin = q * p.queue_chunk;
+                const uint32_t q_end = min(q_begin + p.queue_chunk, p.num_rays);
+                const uint32_t leader = (uint32_t)__builtin_ctzll(need_mask);
+                uint32_t base = 0u;
+                if (lane == leader) base = atomicAdd(queue + 8u * q, (uint32_t)__popcll(need_mask));
+                base = q_begin + (uint32_t)__shfl((int)base, (int)leader, 64);
+                if (base >= q_end || q_begin >= p.num_rays) {      // wave-uniform: this queue is empty
+                    q = (q + 1u) & 7u;
+                    queues_tried++;
+                } else if (need) {
+                    const uint32_t mine = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+                    if (mine < q_end) {                    // lanes past the end stay hungry and try the next queue
+                        const float4 r0 = rays[2 * (size_t)mine], r1 = rays[2 * (size_t)mine + 1];
+                        org = mk(r0.x, r0.y, r0.z); dir = mk(r0.w, r1.x, r1.y);
+                        tmin_r = r1.z; tmax_r = r1.w;
+                        inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                        best.t = tmax_r; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
+                        best_ci = 0u;
+                        if (STATS) { n_nodes++; n_rays++; }
+                        // the trunk is entered on any box hit
+                        if (slab(org, inv_d, tmin_r, tmax_r, root_lo, root_hi) != 1e30f) {
+                            ray = mine; k = root_level - 1u; i = 0u;
+                        } else {
+                            hit_records[mine] = make_float4(best.t, 0.0f, 0.0f, 0.0f);
+                            hit_ci[mine] = 0u;
+                        }
+                    }
+                }
+            }
+        }
+        const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(ray != kNoRay);
+        if (!live_mask) {
+            if (!__builtin_amdgcn_ballot_w64(!exhausted)) break;      // queue empty and nothing in flight: the wave is done
+            continue;
+        }
+
+        // 2. one box test for every walking lane, written without inner branches: descend, park at a leaf or
+        //    pop are selected per lane
+        bool finished = false;
+        if (ray != kNoRay && !parked) {
+            const uint2 level = s_level[k];
+            const bool valid = i < level.y;                    // false: the missing sibling of an only child
+            const size_t node = (size_t)level.x + (valid ? i : 0u);
+            const float4 lo = nodes[2 * node], hi = nodes[2 * node + 1];
+            const float bt = slab(org, inv_d, tmin_r, tmax_r, lo, hi);
+            if (STATS) n_nodes += valid ? 1u : 0u;
+            const bool enter = valid && (bt != 1e30f) && (bt < best.t);
+            const bool descend = enter && k > 0u;
+            uint32_t pk = k, pi = i;
+            const bool root_reached = pop_node(pk, pi, root_level);
+            finished = !enter && root_reached;
+            parked = enter && k == 0u;
+            l0 = parked ? __float_as_uint(hi.z) : l0;
+            l1 = parked ? __float_as_uint(hi.w) : l1;
+            i = descend ? (i << 1) : (enter ? i : pi);
+            k = descend ? (k - 1u) : (enter ? k : pk);
+        }
+
+        // 3. triangle round once enough lanes are parked at leaves (or nobody is walking any more)
+        const unsigned long long parked_mask = __builtin_amdgcn_ballot_w64(parked);
+        if (parked_mask) {
+            const unsigned long long walking_mask = __builtin_amdgcn_ballot_w64(ray != kNoRay && !parked && !finished);
+            if ((uint32_t)__popcll(parked_mask) >= p.leaf_threshold || !walking_mask) {
+                if (parked) {
+                    test_leaf<PACKED>(org, dir, tmin_r, tmax_r, i, l0, l1, indices, verts, sorted_tris, best, best_ci);
+                    if (STATS) n_tris += (l1 != 0xffffffffu) ? 2u : 1u;
+                    parked = false;
+                    finished = pop_node(k, i, root_level);
+                }
+            }
+        }
+
+        // 4. a finished ray leaves its closest hit behind and frees the lane
+        if (finished) {
+            hit_records[ray] = make_float4(best.t, best.u, best.v, best.w);
+            hit_ci[ray] = best_ci;
+            if (STATS && best.t != tmax_r) n_hits++;
+            ray = kNoRay;
+        }
+    }
+    if (STATS) add_stats(stats, n_nodes, n_tris, n_hits, n_rays);
+}
+
+__global__ __launch_bounds__(256) void k_shade(TraceParams p, ShadeBuffers b, const float4* __restrict__ hit_records,
+                                               const uint32_t* __restrict__ hit_ci) {
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    if (tid >= p.num_rays) return;
+    const float4 r0 = b.rays[2 * (size_t)tid], r1 = b.rays[2 * (size_t)tid + 1];
+    const float4 h = hit_records[tid];
+    Hit best;
+    best.t = h.x; best.u = h.y; best.v = h.z; best.w = h.w;
+    shade_ray(p, b, tid, r0, r1, best, hit_ci[tid]);
+}
+
+int trace_workspace(rt_device* dev, uint32_t num_rays) {
+    if (!dev->queue_counter) RT_HIP(hipMalloc((void**)&dev->queue_counter, 256));
+    if (num_rays <= dev->hit_capacity) return RT_OK;
+    RT_HIP(hipStreamSynchronize(dev->stream));
+    if (dev->hit_records) { (void)hipFree(dev->hit_records); dev->hit_records = nullptr; }
+    if (dev->hit_ci) { (void)hipFree(dev->hit_ci); dev->hit_ci = nullptr; }
+    dev->hit_capacity = 0;
+    hipError_t e = hipMalloc((void**)&dev->hit_records, (size_t)num_rays * 16u);
+    if (e == hipSuccess) e = hipMalloc((void**)&dev->hit_ci, (size_t)num_rays * 4u);
+    if (e != hipSuccess) return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
+    dev->hit_capacity = num_rays;
+    return RT_OK;
+}
+
+uint32_t env_u32(const char* name, uint32_t fallback) {
+    const char* v = std::getenv(name);
+    if (!v || !*v) return fallback;
+    return (uint32_t)std::strtoul(v, nullptr, 10);
+}
+
+int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, const rt_accel* accel, const rt_buffer* indices,
+                 const rt_buffer* vertices, const rt_buffer* materials, const rt_buffer* texture_ids,
+                 const rt_buffer* texture_atlas, uint32_t atlas_elements, rt_buffer* rays, rt_buffer* old_rays,
+                 const rt_buffer* ray_pixels, rt_buffer* scattered_light, rt_buffer* emitted_light, const rt_buffer* bvh,
+                 uint32_t first_ray) {
+    if (!dev || !info || !indices || !vertices || !materials || !texture_ids || !texture_atlas || !rays || !old_rays ||
+        !ray_pixels || !scattered_light || !emitted_light)
+        return RT_ERR_INVALID_ARGUMENT;
+    if (use_bvh && !bvh) return RT_ERR_INVALID_ARGUMENT;
+    unsigned long long* stats = dev->trace_stats;
+    const uint32_t nr = info->num_rays;
+    if (rays->bytes < (size_t)nr * 32u || old_rays->bytes < (size_t)nr * 32u || ray_pixels->bytes < (size_t)nr * 4u ||
+        scattered_light->bytes < (size_t)nr * 16u || emitted_light->bytes < (size_t)nr * 16u)
+        return RT_ERR_BUFFER_TOO_SMALL;
+    if (indices->bytes < (size_t)info->num_indices * 4u || texture_atlas->bytes < (size_t)atlas_elements * 16u)
+        return RT_ERR_BUFFER_TOO_SMALL;
+    if (!nr) return RT_OK;
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+
+    // tuning knobs (read once): GPURT_TRACE_KERNEL=simple selects the one-thread-per-ray kernel
+    static const bool simple_kernel = [] { const char* v = std::getenv("GPURT_TRACE_KERNEL"); return v && !std::strcmp(v, "simple"); }();
+    static const uint32_t leaf_threshold = env_u32("GPURT_LEAF_THRESHOLD", 8u);
+    static const uint32_t blocks_per_cu = env_u32("GPURT_BLOCKS_PER_CU", 3u);
+
+    TraceParams p;
+    p.width = info->screen_dimensions[0];
+    p.num_indices = info->num_indices;
+    p.num_rays = nr;
+    p.rpp = info->max_rays_per_pixel;
+    for (int k = 0; k < 3; k++) p.seed[k] = info->rng_seed[k];
+    p.first_ray = first_ray;
+    p.atlas_elems = atlas_elements;
+    p.num_prims = info->num_indices / 3u;
+    p.num_materials = (uint32_t)(materials->bytes / sizeof(rt_pbr_material));
+    p.num_textures = (uint32_t)(texture_ids->bytes / sizeof(rt_texture_id));
+    p.leaf_threshold = leaf_threshold < 1u ? 1u : (leaf_threshold > 64u ? 64u : leaf_threshold);
+    p.queue_chunk = (((nr + 7u) / 8u) + 63u) & ~63u;
+    p.lv.count = 0;
+    if (use_bvh) {
+        if (!rt_make_levels(p.num_prims, &p.lv)) return RT_ERR_TOO_FEW_PRIMITIVES;
+        if (bvh->bytes < (size_t)rt_bvh_node_count(p.num_prims) * 32u) return RT_ERR_BUFFER_TOO_SMALL;
+        if (accel && accel->num_prims != p.num_prims) return RT_ERR_INVALID_ARGUMENT;
+    }
+    ShadeBuffers b;
+    b.indices = (const uint32_t*)indices->ptr;
+    b.verts = (const rt_vertex*)vertices->ptr;
+    b.mats = (const rt_pbr_material*)materials->ptr;
+    b.tex = (const rt_texture_id*)texture_ids->ptr;
+    b.atlas = (const uint4*)texture_atlas->ptr;
+    b.rays = (float4*)rays->ptr;
+    b.old_rays = (float4*)old_rays->ptr;
+    b.ray_pixels = (const uint32_t*)ray_pixels->ptr;
+    b.scattered = (float4*)scattered_light->ptr;
+    b.emitted = (float4*)emitted_light->ptr;
+    const dim3 grid((nr + 255u) / 256u), block(256);
+    const float4* nodes = bvh ? (const float4*)bvh->ptr : nullptr;
+    const float4* st = accel ? (const float4*)accel->sorted_tris : nullptr;
+    if (use_bvh && accel) {
+        // the accel's own copy of the hierarchy keeps every sibling pair in one 64-byte line
+        nodes = (const float4*)accel->anodes;
+        for (uint32_t k = 0; k < p.lv.count; k++) p.lv.off[k] = p.lv.aoff[k];
+    }
+    hipStream_t s = dev->stream;
+
+    if (!use_bvh) {
+        if (stats) hipLaunchKernelGGL((k_trace<false, false, true>), grid, block, 0, s, p, b, nodes, st, stats);
+        else hipLaunchKernelGGL((k_trace<false, false, false>), grid, block, 0, s, p, b, nodes, st, stats);
+        return rt_launch_status();
+    }
+    if (simple_kernel) {
+        if (accel && stats) hipLaunchKernelGGL((k_trace<true, true, true>), grid, block, 0, s, p, b, nodes, st, stats);
+        else if (accel) hipLaunchKernelGGL((k_trace<true, true, false>), grid, block, 0, s, p, b, nodes, st, stats);
+        else if (stats) hipLaunchKernelGGL((k_trace<true, false, true>), grid, block, 0, s, p, b, nodes, st, stats);
+        else hipLaunchKernelGGL((k_trace<true, false, false>), grid, block, 0, s, p, b, nodes, st, stats);
+        return rt_launch_status();
+    }
+
+    rc = trace_workspace(dev, nr);
+    if (rc) return rc;
+    RT_HIP(hipMemsetAsync(dev->queue_counter, 0, 256, s));
+    // persistent grid: enough workgroups to fill every CU, never more than there are rays to hand out
+    hipDeviceProp_t prop;
+    static int cus = 0;
+    if (!cus) { RT_HIP(hipGetDeviceProperties(&prop, dev->gpu)); cus = prop.multiProcessorCount; }
+    uint32_t groups = (uint32_t)cus * (blocks_per_cu ? blocks_per_cu : 1u);
+    if (groups > grid.x) groups = grid.x;
+    const float4* ray_in = (const float4*)rays->ptr;
+    if (accel && stats)
+        hipLaunchKernelGGL((k_traverse<true, true>), dim3(groups), block, 0, s, p, b.indices, b.verts, ray_in, nodes, st,
+                           dev->hit_records, dev->hit_ci, dev->queue_counter, stats);
+    else if (accel)
+        hipLaunchKernelGGL((k_traverse<true, false>), dim3(groups), block, 0, s, p, b.indices, b.verts, ray_in, nodes, st,
+                           dev->hit_records, dev->hit_ci, dev->queue_counter, stats);
+    else if (stats)
+        hipLaunchKernelGGL((k_traverse<false, true>), dim3(groups), block, 0, s, p, b.indices, b.verts, ray_in, nodes, st,
+                           dev->hit_records, dev->hit_ci, dev->queue_counter, stats);
+    else
+        hipLaunchKernelGGL((k_traverse<false, false>), dim3(groups), block, 0, s, p, b.indices, b.verts, ray_in, nodes, st,
+                           dev->hit_records, dev->hit_ci, dev->queue_counter, stats);
+    rc = rt_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_shade, grid, block, 0, s, p, b, (const float4*)dev->hit_records, (const uint32_t*)dev->hit_ci);
+    return rt_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats) {
+    if (!dev || (stats && stats->bytes < 32u)) return RT_ERR_INVALID_ARGUMENT;
+    dev->trace_stats = stats ? (unsigned long long*)stats->ptr : nullptr;
+    return RT_OK;
+}
+
+int rt_trace_rays(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, const rt_buffer* indices,
+                  const rt_buffer* vertices, const rt_buffer* materials, const rt_buffer* texture_ids,
+                  const rt_buffer* texture_atlas, uint32_t atlas_elements, rt_buffer* rays, rt_buffer* old_rays,
+                  const rt_buffer* ray_pixels, rt_buffer* scattered_light, rt_buffer* emitted_light, const rt_buffer* bvh,
+                  uint32_t first_ray) {
+    return trace_common(dev, info, use_bvh, nullptr, indices, vertices, materials, texture_ids, texture_atlas, atlas_elements,
+                        rays, old_rays, ray_pixels, scattered_light, emitted_light, bvh, first_ray);
+}
+
+int rt_trace_rays_accel(rt_device* dev, const rt_trace_rays_info* info, const rt_accel* accel, const rt_buffer* indices,
+                        const rt_buffer* vertices, const rt_buffer* materials, const rt_buffer* texture_ids,
+                        const rt_buffer* texture_atlas, uint32_t atlas_elements, rt_buffer* rays, rt_buffer* old_rays,
+                        const rt_buffer* ray_pixels, rt_buffer* scattered_light, rt_buffer* emitted_light, const rt_buffer* bvh,
+                        uint32_t first_ray) {
+    if (!accel) return RT_ERR_INVALID_ARGUMENT;
+    return trace_common(dev, info, 1, accel, indices, vertices, materials, texture_ids, texture_atlas, atlas_elements, rays,
+                        old_rays, ray_pixels, scattered_light, emitted_light, bvh, first_ray);
+}
+
+}  // extern "C"

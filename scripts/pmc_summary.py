@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Aggregates rocprofv3 --pmc CSV output (one directory per pass) into per-kernel totals.
+Usage: python scripts/pmc_summary.py <dir-with-pass_*> > summary.txt"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"(k_[a-z_0-9]+)", name)
+    return m.group(1) if m else name[:40]
+
+
+def main(root):
+    table = defaultdict(lambda: defaultdict(float))
+    calls = defaultdict(lambda: defaultdict(int))
+    for path in sorted(glob.glob(os.path.join(root, "pass_*", "**", "*counter_collection.csv"), recursive=True)):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                k = short(row["Kernel_Name"])
+                c = row["Counter_Name"]
+                table[k][c] += float(row["Counter_Value"])
+                calls[k][c] += 1
+    for k in sorted(table, key=lambda k: -table[k].get("SQ_WAVE_CYCLES", 0)):
+        print(k)
+        for c in sorted(table[k]):
+            n = calls[k][c]
+            print("    %-36s total %18.0f  per-dispatch %16.1f  (%d dispatches)" % (c, table[k][c], table[k][c] / n, n))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
