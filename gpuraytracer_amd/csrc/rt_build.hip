@@ -15,7 +15,6 @@
 
 namespace {
 
-constexpr int kThreads = RT_SORT_THREADS;
 constexpr int kItems = RT_SORT_ITEMS;
 constexpr int kTile = RT_SORT_TILE;
 
@@ -287,11 +286,38 @@ __device__ __forceinline__ void store_node(rt_aabb* nodes, uint32_t idx, const B
     p[1] = make_float4(b.mx[1], b.mx[2], __uint_as_float(l0), __uint_as_float(l1));
 }
 
+// The accel's private copy of the hierarchy holds sibling pairs: children 2j and 2j+1 of every node share one
+// 64-byte line, components interleaved so that one packed operation covers both boxes:
+//   (min.x0, min.x1, min.y0, min.y1) (min.z0, min.z1, max.x0, max.x1) (max.y0, max.y1, max.z0, max.z1) (links0, links1)
+// The pair of nodes 2j, 2j+1 of level k lives in 32-byte slots aoff[k] + 2j, aoff[k] + 2j + 1.
+__device__ __forceinline__ void store_pair(rt_aabb* pairs, uint32_t slot, const Box& a, const Box& b, uint32_t a0, uint32_t a1,
+                                           uint32_t b0, uint32_t b1) {
+    float4* p = reinterpret_cast<float4*>(pairs + slot);
+    p[0] = make_float4(a.mn[0], b.mn[0], a.mn[1], b.mn[1]);
+    p[1] = make_float4(a.mn[2], b.mn[2], a.mx[0], b.mx[0]);
+    p[2] = make_float4(a.mx[1], b.mx[1], a.mx[2], b.mx[2]);
+    p[3] = make_float4(__uint_as_float(a0), __uint_as_float(a1), __uint_as_float(b0), __uint_as_float(b1));
+}
+// one node's half of its pair (used where the sibling is produced by another workgroup)
+__device__ __forceinline__ void store_pair_half(rt_aabb* pairs, uint32_t pair_slot, uint32_t child, const Box& a, uint32_t a0,
+                                                uint32_t a1) {
+    float* p = reinterpret_cast<float*>(pairs + pair_slot);
+    p[0 + child] = a.mn[0]; p[2 + child] = a.mn[1]; p[4 + child] = a.mn[2];
+    p[6 + child] = a.mx[0]; p[8 + child] = a.mx[1]; p[10 + child] = a.mx[2];
+    p[12 + 2u * child] = __uint_as_float(a0); p[13 + 2u * child] = __uint_as_float(a1);
+}
+__device__ __forceinline__ Box next_lane_box(const Box& b) {
+    Box o;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { o.mn[a] = __shfl_down(b.mn[a], 1, 64); o.mx[a] = __shfl_down(b.mx[a], 1, 64); }
+    return o;
+}
+
 // Builds up to eight levels above level k0 from the (up to) 256 level-k0 boxes the workgroup holds in
 // LDS slot order (slot s <-> node blockIdx.x*256 + s of level k0). Same arithmetic as
 // shader/CS_BVHBuild.hlsl:28-47: min/max union, links (first child, second child or 0xffffffff).
 __device__ __forceinline__ void upsweep_block(Box mine, uint32_t k0, const rt_levels& lv, rt_aabb* __restrict__ nodes,
-                                              rt_aabb* __restrict__ anodes, float (*s_box)[6]) {
+                                              rt_aabb* __restrict__ pairs, float (*s_box)[6]) {
     const uint32_t tid = threadIdx.x;
     uint32_t cnt = 256u;
     uint32_t k = k0;
@@ -305,7 +331,9 @@ __device__ __forceinline__ void upsweep_block(Box mine, uint32_t k0, const rt_le
         k++;
         cnt >>= 1;
         const uint32_t gi = blockIdx.x * cnt + tid;
-        if (tid < cnt && gi < lv.n[k]) {
+        const bool have = tid < cnt && gi < lv.n[k];
+        uint32_t l0 = 0u, l1 = 0u;
+        if (have) {
             const uint32_t c0 = 2u * gi;
             const bool has2 = (c0 + 1u) < lv.n[k - 1];
             const uint32_t s0 = 2u * tid, s1 = has2 ? s0 + 1u : s0;
@@ -314,9 +342,18 @@ __device__ __forceinline__ void upsweep_block(Box mine, uint32_t k0, const rt_le
                 mine.mn[a] = fminf(s_box[s0][a], s_box[s1][a]);
                 mine.mx[a] = fmaxf(s_box[s0][3 + a], s_box[s1][3 + a]);
             }
-            const uint32_t l0 = lv.off[k - 1] + c0;
-            store_node(nodes, lv.off[k] + gi, mine, l0, has2 ? l0 + 1u : 0xffffffffu);
-            if (anodes) store_node(anodes, lv.aoff[k] + gi, mine, l0, has2 ? l0 + 1u : 0xffffffffu);
+            l0 = lv.off[k - 1] + c0;
+            l1 = has2 ? l0 + 1u : 0xffffffffu;
+            store_node(nodes, lv.off[k] + gi, mine, l0, l1);
+        }
+        if (pairs) {                                   // same for the whole grid
+            if (cnt >= 2u) {
+                const Box other = next_lane_box(mine);
+                const uint32_t o0 = __shfl_down(l0, 1, 64), o1 = __shfl_down(l1, 1, 64);
+                if (have && !(gi & 1u)) store_pair(pairs, lv.aoff[k] + gi, mine, other, l0, l1, o0, o1);
+            } else if (have) {
+                store_pair_half(pairs, lv.aoff[k] + (gi & ~1u), gi & 1u, mine, l0, l1);
+            }
         }
     }
 }
@@ -328,17 +365,17 @@ template <bool PACKED, bool FUSED>
 __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv, const uint32_t* __restrict__ sorted,
                                                 const uint32_t* __restrict__ indices, const rt_vertex* __restrict__ verts,
                                                 const float4* __restrict__ tris, float4* __restrict__ sorted_tris,
-                                                rt_aabb* __restrict__ nodes, rt_aabb* __restrict__ anodes) {
+                                                rt_aabb* __restrict__ nodes, rt_aabb* __restrict__ pairs) {
     __shared__ float s_box[256][6];
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t leaves = (num_prims + 1u) / 2u;
     Box b;
 #pragma unroll
     for (int a = 0; a < 3; a++) { b.mn[a] = 1e30f; b.mx[a] = -1e30f; }
+    uint32_t ci0 = 0u, ci1 = 0xffffffffu;
     if (g < leaves) {
         constexpr int STRIDE = PACKED ? 2 : 4;
-        uint32_t ci0 = sorted[(size_t)(2u * g) * STRIDE + 1];
-        uint32_t ci1 = 0xffffffffu;
+        ci0 = sorted[(size_t)(2u * g) * STRIDE + 1];
         const bool two = (2u * g + 1u) < num_prims;
         if (two) ci1 = sorted[(size_t)(2u * g + 1u) * STRIDE + 1];
 #pragma unroll
@@ -359,14 +396,19 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
             b.mx[0] = fmaxf(b.mx[0], px); b.mx[1] = fmaxf(b.mx[1], py); b.mx[2] = fmaxf(b.mx[2], pz);
         }
         store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
-        if (PACKED && anodes) store_node(anodes, lv.aoff[0] + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
     }
-    if (FUSED) upsweep_block(b, 0u, lv, nodes, anodes, s_box);
+    if (PACKED && pairs) {                             // same for the whole grid
+        const Box other = next_lane_box(b);
+        const uint32_t o0 = __shfl_down(ci0, 1, 64), o1 = __shfl_down(ci1, 1, 64);
+        if (g < leaves && !(g & 1u))
+            store_pair(pairs, lv.aoff[0] + g, b, other, ci0 | 0x80000000u, ci1 | 0x80000000u, o0 | 0x80000000u, o1 | 0x80000000u);
+    }
+    if (FUSED) upsweep_block(b, 0u, lv, nodes, pairs, s_box);
 }
 
 // continues the up-sweep from level k0 (already in memory), eight levels per launch
 __global__ __launch_bounds__(256) void k_upsweep(uint32_t k0, rt_levels lv, rt_aabb* __restrict__ nodes,
-                                                 rt_aabb* __restrict__ anodes) {
+                                                 rt_aabb* __restrict__ pairs) {
     __shared__ float s_box[256][6];
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     Box b;
@@ -377,7 +419,7 @@ __global__ __launch_bounds__(256) void k_upsweep(uint32_t k0, rt_levels lv, rt_a
         float4 lo = p[0], hi = p[1];
         b.mn[0] = lo.x; b.mn[1] = lo.y; b.mn[2] = lo.z; b.mx[0] = lo.w; b.mx[1] = hi.x; b.mx[2] = hi.y;
     }
-    upsweep_block(b, k0, lv, nodes, anodes, s_box);
+    upsweep_block(b, k0, lv, nodes, pairs, s_box);
 }
 
 // one level, reference parameters (shader/CS_BVHBuild.hlsl:25-48)
@@ -404,6 +446,26 @@ inline SceneBounds make_bounds(const float* mn, const float* mx) {
 }
 
 }  // namespace
+
+int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted) {
+    int rc = rt_sort_workspace(dev, n);
+    if (rc) return rc;
+    hipStream_t s = dev->stream;
+    const uint32_t tiles = div_up(n, kTile);
+    uint2* src = a;
+    uint2* dst = b;
+    for (uint32_t pass = 0; pass < passes; pass++) {
+        const uint32_t shift = 8u * pass;
+        hipLaunchKernelGGL((k_sort_hist<2, false>), dim3(tiles), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)nullptr, n,
+                           shift, dev->sort_table, tiles, (uint4*)nullptr);
+        hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, s, dev->sort_table, tiles, dev->sort_totals);
+        hipLaunchKernelGGL((k_sort_scatter<2, 2, false>), dim3(tiles), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, n,
+                           shift, dev->sort_table, tiles, dev->sort_totals, (uint4*)nullptr);
+        uint2* t = src; src = dst; dst = t;
+    }
+    *sorted = src;
+    return rt_launch_status();
+}
 
 extern "C" {
 
@@ -532,7 +594,7 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
     a->num_prims = 0;
     a->tris = a->sorted_tris = nullptr;
     a->keys_a = a->keys_b = nullptr;
-    a->anodes = nullptr;
+    a->pairs = nullptr;
     const size_t tri_bytes = (size_t)max_primitives * 48u, key_bytes = (size_t)max_primitives * 8u;
     hipError_t e = hipMalloc((void**)&a->tris, tri_bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&a->sorted_tris, tri_bytes + 48u);   // odd counts pad the last leaf
@@ -542,7 +604,7 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
         rt_levels lv;
         rt_make_levels(max_primitives, &lv);
         // a smaller scene packed later never needs more slots than the largest one
-        if (e == hipSuccess) e = hipMalloc((void**)&a->anodes, (rt_aligned_node_slots(&lv) + 64u) * sizeof(rt_aabb));
+        if (e == hipSuccess) e = hipMalloc((void**)&a->pairs, (rt_aligned_node_slots(&lv) + 64u) * sizeof(rt_aabb));
     }
     if (e != hipSuccess) {
         rt_accel_destroy(a);
@@ -560,7 +622,7 @@ int rt_accel_destroy(rt_accel* a) {
     if (a->sorted_tris) (void)hipFree(a->sorted_tris);
     if (a->keys_a) (void)hipFree(a->keys_a);
     if (a->keys_b) (void)hipFree(a->keys_b);
-    if (a->anodes) (void)hipFree(a->anodes);
+    if (a->pairs) (void)hipFree(a->pairs);
     delete a;
     return RT_OK;
 }
@@ -592,24 +654,14 @@ int rt_accel_build(rt_accel* a, const float scene_min[3], const float scene_max[
 
     hipLaunchKernelGGL(k_morton_packed, dim3(div_up(n, 256u)), dim3(256), 0, s, make_bounds(scene_min, scene_max), n, a->tris,
                        a->keys_a);
-    const uint32_t tiles = div_up(n, kTile);
-    uint2* src = a->keys_a;
-    uint2* dst = a->keys_b;
-    for (uint32_t pass = 0; pass < 4u; pass++) {
-        const uint32_t shift = 8u * pass;
-        hipLaunchKernelGGL((k_sort_hist<2, false>), dim3(tiles), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)nullptr, n,
-                           shift, dev->sort_table, tiles, (uint4*)nullptr);
-        hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, s, dev->sort_table, tiles, dev->sort_totals);
-        hipLaunchKernelGGL((k_sort_scatter<2, 2, false>), dim3(tiles), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, n,
-                           shift, dev->sort_table, tiles, dev->sort_totals, (uint4*)nullptr);
-        uint2* t = src; src = dst; dst = t;
-    }
-    // four passes: the sorted pairs are back in keys_a (= src)
+    uint2* src = nullptr;
+    rc = rt_sort_pairs(dev, a->keys_a, a->keys_b, n, 4u, &src);     // four passes: the sorted pairs are back in keys_a
+    if (rc) return rc;
     const uint32_t leaves = lv.n[0];
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)src,
-                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, a->anodes);
+                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, a->pairs);
     for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
-        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, a->anodes);
+        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, a->pairs);
     if (morton_codes)
         hipLaunchKernelGGL(k_expand_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, n, src, (uint4*)morton_codes->ptr);
     return rt_launch_status();

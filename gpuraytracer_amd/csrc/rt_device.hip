@@ -28,6 +28,8 @@ int rt_device_create(int gpu_index, rt_device** out) {
     d->hit_ci = nullptr;
     d->hit_capacity = 0;
     d->queue_counter = nullptr;
+    d->ray_keys_a = nullptr;
+    d->ray_keys_b = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete d; return RT_ERR_HIP_BASE + (int)e; }
     e = hipMalloc((void**)&d->sort_totals, 512 * sizeof(uint32_t));
@@ -46,6 +48,8 @@ int rt_device_destroy(rt_device* dev) {
     if (dev->hit_records) (void)hipFree(dev->hit_records);
     if (dev->hit_ci) (void)hipFree(dev->hit_ci);
     if (dev->queue_counter) (void)hipFree(dev->queue_counter);
+    if (dev->ray_keys_a) (void)hipFree(dev->ray_keys_a);
+    if (dev->ray_keys_b) (void)hipFree(dev->ray_keys_b);
     if (dev->owns_stream && dev->stream) (void)hipStreamDestroy(dev->stream);
     delete dev;
     return RT_OK;

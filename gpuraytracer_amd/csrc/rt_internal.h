@@ -20,7 +20,9 @@ struct rt_device {
     float4* hit_records;       // [hit_capacity] (t, u, v, facing)
     uint32_t* hit_ci;          // [hit_capacity] first index slot of the hit triangle
     size_t hit_capacity;
-    uint32_t* queue_counter;   // ray queue head of the persistent traversal kernel (256 bytes)
+    uint32_t* queue_counter;   // ray queue heads of the persistent traversal kernel (256 bytes)
+    uint2* ray_keys_a;         // [hit_capacity] (locality key, ray index) pairs: the order rays are handed out in
+    uint2* ray_keys_b;
 };
 
 struct rt_buffer {
@@ -41,7 +43,7 @@ struct rt_accel {
     uint32_t num_prims;        // set by rt_accel_pack
     float4* tris;              // [3*max_prims] packed positions, original order
     float4* sorted_tris;       // [3*max_prims] packed positions, Morton order (w of vertex 0 = 3*tri)
-    rt_aabb* anodes;           // pair-aligned private copy of the hierarchy (rt_levels::aoff placement)
+    rt_aabb* pairs;            // private copy of the hierarchy as interleaved sibling pairs (rt_levels::aoff placement)
     uint2* keys_a;             // [max_prims] (code, 3*tri)
     uint2* keys_b;             // [max_prims]
 };
@@ -69,13 +71,17 @@ static inline int rt_launch_status() {
 #define RT_SORT_TILE (RT_SORT_THREADS * RT_SORT_ITEMS)
 
 int rt_sort_workspace(rt_device* dev, uint32_t num_elements);   // grows dev->sort_table as needed
+// Stable LSD radix sort of (key, value) pairs by the low 8 * passes key bits, queued on the device's stream.
+// a and b hold n pairs each and are both overwritten; *sorted receives whichever of them holds the result.
+int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted);
 
 // level schedule of the balanced hierarchy (src/RaytracerPipeline.cpp:465-467, 497-559):
 // level 0 = leaves at node 1; level k has ceil(n_{k-1} / 2) nodes appended after level k-1;
 // the level holding a single node is the root and is stored at node 0.
 //
 // aoff is a second, private placement of the same nodes used by the accel's own copy: every level starts at
-// an even slot, so the sibling pair (2j, 2j+1) of any level shares one 64-byte line.
+// an even 32-byte slot, so the sibling pair (2j, 2j+1) of any level shares one 64-byte line (slots aoff + 2j and
+// aoff + 2j + 1), which holds the two boxes with their components interleaved.
 struct rt_levels {
     uint32_t count;            // number of levels including the root level
     uint32_t n[33];            // nodes per level

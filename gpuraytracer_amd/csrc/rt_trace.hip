@@ -358,28 +358,99 @@ __global__ __launch_bounds__(256) void k_trace(TraceParams p, ShadeBuffers b, co
 
 constexpr uint32_t kNoRay = 0xffffffffu;
 
+// Leaf of the wavefront kernel, identified by its index in level 0. PACKED takes the slot of each triangle's
+// first index from the w component of its first packed vertex; otherwise the links of the leaf's node.
+template <bool PACKED>
+__device__ __forceinline__ uint32_t test_leaf_by_index(f3 org, f3 dir, float tmin_r, float tmax_r, uint32_t leaf, uint32_t num_prims,
+                                                       uint32_t leaf_base, const float4* __restrict__ nodes,
+                                                       const uint32_t* __restrict__ indices, const rt_vertex* __restrict__ verts,
+                                                       const float4* __restrict__ sorted_tris, Hit& best, uint32_t& best_ci) {
+    if (PACKED) {
+        const float4* t = sorted_tris + 6 * (size_t)leaf;
+        const bool two = 2u * leaf + 1u < num_prims;
+        const float4 a0 = t[0], b0 = t[1], c0 = t[2];
+        float4 a1 = a0, b1 = b0, c1 = c0;
+        if (two) { a1 = t[3]; b1 = t[4]; c1 = t[5]; }
+        check_hit(intersect_tri(org, dir, mk(a0.x, a0.y, a0.z), mk(b0.x, b0.y, b0.z), mk(c0.x, c0.y, c0.z)), tmin_r, tmax_r,
+                  __float_as_uint(a0.w), best, best_ci);
+        if (two)
+            check_hit(intersect_tri(org, dir, mk(a1.x, a1.y, a1.z), mk(b1.x, b1.y, b1.z), mk(c1.x, c1.y, c1.z)), tmin_r, tmax_r,
+                      __float_as_uint(a1.w), best, best_ci);
+        return two ? 2u : 1u;
+    } else {
+        const float4 hi = nodes[2 * ((size_t)leaf_base + leaf) + 1];
+        const uint32_t l0 = __float_as_uint(hi.z), l1 = __float_as_uint(hi.w);
+        test_leaf<false>(org, dir, tmin_r, tmax_r, leaf, l0, l1, indices, verts, sorted_tris, best, best_ci);
+        return (l1 != 0xffffffffu) ? 2u : 1u;
+    }
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// shader/CS_TraceRays.hlsl:81-97 for both boxes of an interleaved sibling pair at once (same operations per
+// box as slab(); the subtractions and multiplications cover the two boxes with one packed instruction each)
+__device__ __forceinline__ void slab_pair(f3 o, f3 inv_d, float tmin_r, float tmax_r, float4 q0, float4 q1, float4 q2, float& bt0,
+                                          float& bt1) {
+    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const v2f ix = {inv_d.x, inv_d.x}, iy = {inv_d.y, inv_d.y}, iz = {inv_d.z, inv_d.z};
+    const v2f ax = (v2f{q0.x, q0.y} - ox) * ix, ay = (v2f{q0.z, q0.w} - oy) * iy, az = (v2f{q1.x, q1.y} - oz) * iz;
+    const v2f bx = (v2f{q1.z, q1.w} - ox) * ix, by = (v2f{q2.x, q2.y} - oy) * iy, bz = (v2f{q2.z, q2.w} - oz) * iz;
+    float tn0 = fmaxf(fminf(ax.x, bx.x), fmaxf(fminf(ay.x, by.x), fminf(az.x, bz.x)));
+    float tn1 = fmaxf(fminf(ax.y, bx.y), fmaxf(fminf(ay.y, by.y), fminf(az.y, bz.y)));
+    const float tx0 = fminf(fmaxf(ax.x, bx.x), fminf(fmaxf(ay.x, by.x), fmaxf(az.x, bz.x)));
+    const float tx1 = fminf(fmaxf(ax.y, bx.y), fminf(fmaxf(ay.y, by.y), fmaxf(az.y, bz.y)));
+    if ((tx0 < tn0) || (tx0 <= 0.0f) || (tx0 < tmin_r) || (tn0 > tmax_r)) tn0 = 1e30f;
+    if ((tx1 < tn1) || (tx1 <= 0.0f) || (tx1 < tmin_r) || (tn1 > tmax_r)) tn1 = 1e30f;
+    bt0 = tn0; bt1 = tn1;
+}
+
+constexpr uint32_t kFifo = 8u;        // leaves a lane may have waiting for a triangle round
+
+// One step of a lane handles the two children of the node it has entered: both boxes are tested at once (the
+// reference tests the second one when its walk comes back to it, which it always does); of two children that
+// are hit, the walk goes into the first and notes the second's entry distance, to be compared with the closest
+// hit again when the walk returns. A lane that finds a leaf hit notes (leaf, entry distance) in a first-in
+// first-out list and walks on; once enough lanes of the wave have a leaf waiting, each of them tests its
+// oldest one, after comparing the noted distance with its closest hit again.
+//
+// This tests exactly the triangles of the reference's walk (shader/CS_TraceRays.hlsl:179-237), in its order:
+// box entry distances never decrease from a node to its descendants and the closest hit only shrinks, so a
+// leaf passes its delayed comparison exactly if it and all of its ancestors pass theirs in the reference's
+// walk, whose order of leaves (left child first) is the order of the list. Walking on with a closest hit that
+// is out of date only adds box tests. The counting variant walks only while no leaf is waiting, which makes
+// its box tests those of the reference's walk, too.
+//
+// PACKED: interleaved sibling pairs, Morton-ordered packed triangles; otherwise the reference's buffers.
 template <bool PACKED, bool STATS>
 __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const uint32_t* __restrict__ indices,
                                                   const rt_vertex* __restrict__ verts, const float4* __restrict__ rays,
-                                                  const float4* __restrict__ nodes, const float4* __restrict__ sorted_tris,
-                                                  float4* __restrict__ hit_records, uint32_t* __restrict__ hit_ci,
-                                                  uint32_t* __restrict__ queue, unsigned long long* __restrict__ stats) {
-    __shared__ uint2 s_level[33];                  // (first node, node count) of every level
-    if (threadIdx.x < 33u) s_level[threadIdx.x] = make_uint2(p.lv.off[threadIdx.x], p.lv.n[threadIdx.x]);
+                                                  const float4* __restrict__ nodes, const float4* __restrict__ pairs,
+                                                  const float4* __restrict__ sorted_tris, float4* __restrict__ hit_records,
+                                                  uint32_t* __restrict__ hit_ci, uint32_t* __restrict__ queue,
+                                                  const uint2* __restrict__ order, unsigned long long* __restrict__ stats) {
+    extern __shared__ uint32_t s_dyn[];
+    __shared__ uint2 s_level[33];                  // (first slot, node count) of every level
+    if (threadIdx.x < 33u)
+        s_level[threadIdx.x] = make_uint2(PACKED ? p.lv.aoff[threadIdx.x] : p.lv.off[threadIdx.x], p.lv.n[threadIdx.x]);
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t root_level = p.lv.count - 1u;
+    float* s_far = reinterpret_cast<float*>(s_dyn);                          // [root_level][256] noted second children
+    uint2* s_fifo = reinterpret_cast<uint2*>(s_dyn + root_level * 256u);     // [kFifo][256] waiting leaves
     const float4 root_lo = nodes[0], root_hi = nodes[1];
 
     uint32_t ray = kNoRay;            // index of the ray this lane is walking
     bool exhausted = false;           // the queue had no ray left for this lane
-    bool parked = false;              // waiting at a leaf for the wave's next triangle round
+    bool walk_done = false;           // the walk is over; waiting leaves may remain
+    bool popping = false;             // the subtree of (k, i) is finished: go to the nearest noted second child
     f3 org = mk(0.0f, 0.0f, 0.0f), dir = org, inv_d = org;
     float tmin_r = 0.0f, tmax_r = 0.0f;
     Hit best;
     best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
-    uint32_t best_ci = 0u, k = 0u, i = 0u, l0 = 0u, l1 = 0u;
+    uint32_t best_ci = 0u, k = 0u, i = 0u;
+    uint32_t noted = 0u;              // bit j: the second child of the walk's ancestor at level j + 1 is noted in s_far[j]
+    uint32_t wait_head = 0u, wait_n = 0u;
     uint32_t n_nodes = 0u, n_tris = 0u, n_hits = 0u, n_rays = 0u;
     uint32_t q = blockIdx.x & 7u, queues_tried = 0u;       // wave-uniform
 
@@ -407,7 +478,8 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const uint32_t*
                     const uint32_t mine = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
                                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
                     if (mine < q_end) {                    // lanes past the end stay hungry and try the next queue
-                        const float4 r0 = rays[2 * (size_t)mine], r1 = rays[2 * (size_t)mine + 1];
+                        const uint32_t rid = order ? order[mine].y : mine;     // queue position -> ray
+                        const float4 r0 = rays[2 * (size_t)rid], r1 = rays[2 * (size_t)rid + 1];
                         org = mk(r0.x, r0.y, r0.z); dir = mk(r0.w, r1.x, r1.y);
                         tmin_r = r1.z; tmax_r = r1.w;
                         inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
@@ -416,10 +488,11 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const uint32_t*
                         if (STATS) { n_nodes++; n_rays++; }
                         // the trunk is entered on any box hit
                         if (slab(org, inv_d, tmin_r, tmax_r, root_lo, root_hi) != 1e30f) {
-                            ray = mine; k = root_level - 1u; i = 0u;
+                            ray = rid; k = root_level; i = 0u;
+                            walk_done = false; popping = false; noted = 0u;
                         } else {
-                            hit_records[mine] = make_float4(best.t, 0.0f, 0.0f, 0.0f);
-                            hit_ci[mine] = 0u;
+                            hit_records[rid] = make_float4(best.t, 0.0f, 0.0f, 0.0f);
+                            hit_ci[rid] = 0u;
                         }
                     }
                 }
@@ -431,44 +504,85 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const uint32_t*
             continue;
         }
 
-        // 2. one box test for every walking lane, written without inner branches: descend, park at a leaf or
-        //    pop are selected per lane
-        bool finished = false;
-        if (ray != kNoRay && !parked) {
-            const uint2 level = s_level[k];
-            const bool valid = i < level.y;                    // false: the missing sibling of an only child
-            const size_t node = (size_t)level.x + (valid ? i : 0u);
-            const float4 lo = nodes[2 * node], hi = nodes[2 * node + 1];
-            const float bt = slab(org, inv_d, tmin_r, tmax_r, lo, hi);
-            if (STATS) n_nodes += valid ? 1u : 0u;
-            const bool enter = valid && (bt != 1e30f) && (bt < best.t);
-            const bool descend = enter && k > 0u;
-            uint32_t pk = k, pi = i;
-            const bool root_reached = pop_node(pk, pi, root_level);
-            finished = !enter && root_reached;
-            parked = enter && k == 0u;
-            l0 = parked ? __float_as_uint(hi.z) : l0;
-            l1 = parked ? __float_as_uint(hi.w) : l1;
-            i = descend ? (i << 1) : (enter ? i : pi);
-            k = descend ? (k - 1u) : (enter ? k : pk);
+        // 2. the two children of the entered node (k, i)
+        const bool can_walk = ray != kNoRay && !walk_done && (STATS ? wait_n == 0u : wait_n + 2u <= kFifo);
+        if (can_walk && !popping) {
+            const uint32_t kc = k - 1u;
+            const uint2 level = s_level[kc];
+            const uint32_t c0 = 2u * i;
+            const bool valid1 = c0 + 1u < level.y;             // false: an only child
+            float bt0, bt1;
+            if (PACKED) {
+                const float4* qp = pairs + 2 * ((size_t)level.x + c0);
+                slab_pair(org, inv_d, tmin_r, tmax_r, qp[0], qp[1], qp[2], bt0, bt1);
+            } else {
+                const float4* n0 = nodes + 2 * ((size_t)level.x + c0);
+                const float4* n1 = n0 + (valid1 ? 2 : 0);
+                bt0 = slab(org, inv_d, tmin_r, tmax_r, n0[0], n0[1]);
+                bt1 = slab(org, inv_d, tmin_r, tmax_r, n1[0], n1[1]);
+            }
+            if (STATS) n_nodes += valid1 ? 2u : 1u;
+            const bool hit0 = (bt0 != 1e30f) && (bt0 < best.t);
+            const bool hit1 = valid1 && (bt1 != 1e30f) && (bt1 < best.t);
+            if (kc == 0u) {                                     // the children are leaves
+                if (hit0) {
+                    s_fifo[((wait_head + wait_n) & (kFifo - 1u)) * 256u + tid] = make_uint2(c0, __float_as_uint(bt0));
+                    wait_n++;
+                }
+                if (hit1) {
+                    s_fifo[((wait_head + wait_n) & (kFifo - 1u)) * 256u + tid] = make_uint2(c0 + 1u, __float_as_uint(bt1));
+                    wait_n++;
+                }
+                popping = true;
+            } else {
+                if (hit0 && hit1) {
+                    s_far[kc * 256u + tid] = bt1;
+                    noted |= 1u << kc;
+                }
+                const bool go = hit0 || hit1;
+                i = go ? (c0 + (hit0 ? 0u : 1u)) : i;
+                k = go ? kc : k;
+                popping = !go;
+            }
         }
 
-        // 3. triangle round once enough lanes are parked at leaves (or nobody is walking any more)
-        const unsigned long long parked_mask = __builtin_amdgcn_ballot_w64(parked);
-        if (parked_mask) {
-            const unsigned long long walking_mask = __builtin_amdgcn_ballot_w64(ray != kNoRay && !parked && !finished);
-            if ((uint32_t)__popcll(parked_mask) >= p.leaf_threshold || !walking_mask) {
-                if (parked) {
-                    test_leaf<PACKED>(org, dir, tmin_r, tmax_r, i, l0, l1, indices, verts, sorted_tris, best, best_ci);
-                    if (STATS) n_tris += (l1 != 0xffffffffu) ? 2u : 1u;
-                    parked = false;
-                    finished = pop_node(k, i, root_level);
+        // 3. back to the nearest noted second child; it is entered if it still starts before the closest hit
+        //    (the counting variant first lets the leaves found in this step be tested)
+        if (can_walk && popping && (!STATS || wait_n == 0u)) {
+            if (!noted) {
+                walk_done = true;
+                popping = false;
+            } else {
+                const uint32_t j = (uint32_t)__builtin_ctz(noted);
+                noted &= noted - 1u;
+                const float bt = s_far[j * 256u + tid];
+                i = (i >> (j - k)) | 1u;
+                k = j;
+                popping = !(bt < best.t);
+            }
+        }
+
+        // 4. triangle round once enough lanes have a leaf waiting (or nobody can walk any more)
+        const unsigned long long waiting_mask = __builtin_amdgcn_ballot_w64(wait_n > 0u);
+        if (waiting_mask) {
+            const unsigned long long walking_mask =
+                __builtin_amdgcn_ballot_w64(ray != kNoRay && !walk_done && (STATS ? wait_n == 0u : wait_n + 2u <= kFifo));
+            if ((uint32_t)__popcll(waiting_mask) >= p.leaf_threshold || !walking_mask) {
+                if (wait_n > 0u) {
+                    const uint2 e = s_fifo[wait_head * 256u + tid];
+                    wait_head = (wait_head + 1u) & (kFifo - 1u);
+                    wait_n--;
+                    if (__uint_as_float(e.y) < best.t) {
+                        const uint32_t tested = test_leaf_by_index<PACKED>(org, dir, tmin_r, tmax_r, e.x, p.num_prims, p.lv.off[0], nodes,
+                                                                           indices, verts, sorted_tris, best, best_ci);
+                        if (STATS) n_tris += tested;
+                    }
                 }
             }
         }
 
-        // 4. a finished ray leaves its closest hit behind and frees the lane
-        if (finished) {
+        // 5. a finished ray leaves its closest hit behind and frees the lane
+        if (ray != kNoRay && walk_done && wait_n == 0u) {
             hit_records[ray] = make_float4(best.t, best.u, best.v, best.w);
             hit_ci[ray] = best_ci;
             if (STATS && best.t != tmax_r) n_hits++;
@@ -476,6 +590,34 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const uint32_t*
         }
     }
     if (STATS) add_stats(stats, n_nodes, n_tris, n_hits, n_rays);
+}
+
+// Locality key of every ray for the order the traversal queues hand rays out in (the reference has no such
+// step; the order rays are traced in does not enter any result). Rays that start in the same cell of a
+// 32^3 grid over the trunk's box and point into the same of 8^3 direction cells get neighbouring queue
+// positions, so the lanes of a wave, and the waves of an XCD, walk the same part of the hierarchy.
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {      // abcde -> a00b00c00d00e
+    v = (v | (v << 8)) & 0x0000f00fu;
+    v = (v | (v << 4)) & 0x000c30c3u;
+    v = (v | (v << 2)) & 0x00249249u;
+    return v;
+}
+__global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float4* __restrict__ rays,
+                                                  const float4* __restrict__ nodes, uint2* __restrict__ keys) {
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    if (tid >= num_rays) return;
+    const float4 lo = nodes[0], hi = nodes[1];
+    const float4 r0 = rays[2 * (size_t)tid], r1 = rays[2 * (size_t)tid + 1];
+    const float cx = (r0.x - lo.x) / (lo.w - lo.x), cy = (r0.y - lo.y) / (hi.x - lo.y), cz = (r0.z - lo.z) / (hi.y - lo.z);
+    const uint32_t ox = (uint32_t)fminf(fmaxf(cx * 32.0f, 0.0f), 31.0f);
+    const uint32_t oy = (uint32_t)fminf(fmaxf(cy * 32.0f, 0.0f), 31.0f);
+    const uint32_t oz = (uint32_t)fminf(fmaxf(cz * 32.0f, 0.0f), 31.0f);
+    const uint32_t dx = (uint32_t)fminf(fmaxf(r0.w * 4.0f + 4.0f, 0.0f), 7.0f);
+    const uint32_t dy = (uint32_t)fminf(fmaxf(r1.x * 4.0f + 4.0f, 0.0f), 7.0f);
+    const uint32_t dz = (uint32_t)fminf(fmaxf(r1.y * 4.0f + 4.0f, 0.0f), 7.0f);
+    const uint32_t okey = spread3(ox) | (spread3(oy) << 1) | (spread3(oz) << 2);
+    const uint32_t dkey = spread3(dx) | (spread3(dy) << 1) | (spread3(dz) << 2);
+    keys[tid] = make_uint2((okey << 9) | dkey, tid);
 }
 
 __global__ __launch_bounds__(256) void k_shade(TraceParams p, ShadeBuffers b, const float4* __restrict__ hit_records,
@@ -495,9 +637,13 @@ int trace_workspace(rt_device* dev, uint32_t num_rays) {
     RT_HIP(hipStreamSynchronize(dev->stream));
     if (dev->hit_records) { (void)hipFree(dev->hit_records); dev->hit_records = nullptr; }
     if (dev->hit_ci) { (void)hipFree(dev->hit_ci); dev->hit_ci = nullptr; }
+    if (dev->ray_keys_a) { (void)hipFree(dev->ray_keys_a); dev->ray_keys_a = nullptr; }
+    if (dev->ray_keys_b) { (void)hipFree(dev->ray_keys_b); dev->ray_keys_b = nullptr; }
     dev->hit_capacity = 0;
     hipError_t e = hipMalloc((void**)&dev->hit_records, (size_t)num_rays * 16u);
     if (e == hipSuccess) e = hipMalloc((void**)&dev->hit_ci, (size_t)num_rays * 4u);
+    if (e == hipSuccess) e = hipMalloc((void**)&dev->ray_keys_a, (size_t)num_rays * 8u);
+    if (e == hipSuccess) e = hipMalloc((void**)&dev->ray_keys_b, (size_t)num_rays * 8u);
     if (e != hipSuccess) return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
     dev->hit_capacity = num_rays;
     return RT_OK;
@@ -531,8 +677,9 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
 
     // tuning knobs (read once): GPURT_TRACE_KERNEL=simple selects the one-thread-per-ray kernel
     static const bool simple_kernel = [] { const char* v = std::getenv("GPURT_TRACE_KERNEL"); return v && !std::strcmp(v, "simple"); }();
-    static const uint32_t leaf_threshold = env_u32("GPURT_LEAF_THRESHOLD", 8u);
+    static const uint32_t leaf_threshold = env_u32("GPURT_LEAF_THRESHOLD", 16u);
     static const uint32_t blocks_per_cu = env_u32("GPURT_BLOCKS_PER_CU", 3u);
+    static const uint32_t sort_rays = env_u32("GPURT_SORT_RAYS", 1u);
 
     TraceParams p;
     p.width = info->screen_dimensions[0];
@@ -567,11 +714,6 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     const dim3 grid((nr + 255u) / 256u), block(256);
     const float4* nodes = bvh ? (const float4*)bvh->ptr : nullptr;
     const float4* st = accel ? (const float4*)accel->sorted_tris : nullptr;
-    if (use_bvh && accel) {
-        // the accel's own copy of the hierarchy keeps every sibling pair in one 64-byte line
-        nodes = (const float4*)accel->anodes;
-        for (uint32_t k = 0; k < p.lv.count; k++) p.lv.off[k] = p.lv.aoff[k];
-    }
     hipStream_t s = dev->stream;
 
     if (!use_bvh) {
@@ -597,18 +739,22 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     uint32_t groups = (uint32_t)cus * (blocks_per_cu ? blocks_per_cu : 1u);
     if (groups > grid.x) groups = grid.x;
     const float4* ray_in = (const float4*)rays->ptr;
-    if (accel && stats)
-        hipLaunchKernelGGL((k_traverse<true, true>), dim3(groups), block, 0, s, p, b.indices, b.verts, ray_in, nodes, st,
-                           dev->hit_records, dev->hit_ci, dev->queue_counter, stats);
-    else if (accel)
-        hipLaunchKernelGGL((k_traverse<true, false>), dim3(groups), block, 0, s, p, b.indices, b.verts, ray_in, nodes, st,
-                           dev->hit_records, dev->hit_ci, dev->queue_counter, stats);
-    else if (stats)
-        hipLaunchKernelGGL((k_traverse<false, true>), dim3(groups), block, 0, s, p, b.indices, b.verts, ray_in, nodes, st,
-                           dev->hit_records, dev->hit_ci, dev->queue_counter, stats);
-    else
-        hipLaunchKernelGGL((k_traverse<false, false>), dim3(groups), block, 0, s, p, b.indices, b.verts, ray_in, nodes, st,
-                           dev->hit_records, dev->hit_ci, dev->queue_counter, stats);
+    uint2* order = nullptr;
+    if (sort_rays) {
+        hipLaunchKernelGGL(k_ray_keys, grid, block, 0, s, nr, ray_in, nodes, dev->ray_keys_a);
+        rc = rt_sort_pairs(dev, dev->ray_keys_a, dev->ray_keys_b, nr, 3u, &order);      // 24-bit keys
+        if (rc) return rc;
+    }
+    const size_t lds_bytes = ((size_t)(p.lv.count - 1u) * 256u + (size_t)kFifo * 512u) * sizeof(uint32_t);
+    const float4* pairs = accel ? (const float4*)accel->pairs : nullptr;
+#define RT_LAUNCH_TRAVERSE(PACKED, STATS)                                                                                       \
+    hipLaunchKernelGGL((k_traverse<PACKED, STATS>), dim3(groups), block, lds_bytes, s, p, b.indices, b.verts, ray_in, nodes, pairs, \
+                       st, dev->hit_records, dev->hit_ci, dev->queue_counter, order, stats)
+    if (accel && stats) RT_LAUNCH_TRAVERSE(true, true);
+    else if (accel) RT_LAUNCH_TRAVERSE(true, false);
+    else if (stats) RT_LAUNCH_TRAVERSE(false, true);
+    else RT_LAUNCH_TRAVERSE(false, false);
+#undef RT_LAUNCH_TRAVERSE
     rc = rt_launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(k_shade, grid, block, 0, s, p, b, (const float4*)dev->hit_records, (const uint32_t*)dev->hit_ci);

@@ -10,8 +10,8 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(k_[a-z_0-9]+)", name)
-    return m.group(1) if m else name[:40]
+    m = re.search(r"(k_[a-z_0-9]+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:40]
 
 
 def main(root):
