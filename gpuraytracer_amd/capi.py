@@ -87,6 +87,8 @@ SIGNATURES = {
     "rt_device_index": (C.c_int, [_P]),
     "rt_error_string": (C.c_char_p, [C.c_int]),
     "rt_device_set_trace_stats": (C.c_int, [_P, _P]),
+    "rt_device_set_traverse_timing": (C.c_int, [_P, C.c_int]),
+    "rt_device_traverse_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "rt_event_create": (C.c_int, [_P, C.POINTER(_P)]),
     "rt_event_record": (C.c_int, [_P]),
     "rt_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),

@@ -306,10 +306,17 @@ __device__ __forceinline__ void store_pair_half(rt_aabb* pairs, uint32_t pair_sl
     p[6 + child] = a.mx[0]; p[8 + child] = a.mx[1]; p[10 + child] = a.mx[2];
     p[12 + 2u * child] = __uint_as_float(a0); p[13 + 2u * child] = __uint_as_float(a1);
 }
-__device__ __forceinline__ Box next_lane_box(const Box& b) {
+// the next lane's box, or - where the next node does not exist - a box of NaNs, which no box built from
+// vertices can be (min/max drop NaN operands); the walk recognises a missing child by it
+__device__ __forceinline__ Box next_lane_box(const Box& b, bool exists) {
     Box o;
+    const float nan = __uint_as_float(0x7fc00000u);
 #pragma unroll
-    for (int a = 0; a < 3; a++) { o.mn[a] = __shfl_down(b.mn[a], 1, 64); o.mx[a] = __shfl_down(b.mx[a], 1, 64); }
+    for (int a = 0; a < 3; a++) {
+        const float mn = __shfl_down(b.mn[a], 1, 64), mx = __shfl_down(b.mx[a], 1, 64);     // by every lane
+        o.mn[a] = exists ? mn : nan;
+        o.mx[a] = exists ? mx : nan;
+    }
     return o;
 }
 
@@ -346,13 +353,18 @@ __device__ __forceinline__ void upsweep_block(Box mine, uint32_t k0, const rt_le
             l1 = has2 ? l0 + 1u : 0xffffffffu;
             store_node(nodes, lv.off[k] + gi, mine, l0, l1);
         }
-        if (pairs) {                                   // same for the whole grid
+        if (pairs && k + 1u < lv.count) {              // same for the whole grid; the trunk is in nobody's record
             if (cnt >= 2u) {
-                const Box other = next_lane_box(mine);
+                const Box other = next_lane_box(mine, gi + 1u < lv.n[k]);
                 const uint32_t o0 = __shfl_down(l0, 1, 64), o1 = __shfl_down(l1, 1, 64);
                 if (have && !(gi & 1u)) store_pair(pairs, lv.aoff[k] + gi, mine, other, l0, l1, o0, o1);
             } else if (have) {
                 store_pair_half(pairs, lv.aoff[k] + (gi & ~1u), gi & 1u, mine, l0, l1);
+                if (!(gi & 1u) && gi + 1u >= lv.n[k]) {        // an only child: mark the other half as missing
+                    Box none;
+                    for (int a = 0; a < 3; a++) none.mn[a] = none.mx[a] = __uint_as_float(0x7fc00000u);
+                    store_pair_half(pairs, lv.aoff[k] + gi, 1u, none, 0xffffffffu, 0xffffffffu);
+                }
             }
         }
     }
@@ -398,7 +410,7 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
         store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
     }
     if (PACKED && pairs) {                             // same for the whole grid
-        const Box other = next_lane_box(b);
+        const Box other = next_lane_box(b, g + 1u < leaves);
         const uint32_t o0 = __shfl_down(ci0, 1, 64), o1 = __shfl_down(ci1, 1, 64);
         if (g < leaves && !(g & 1u))
             store_pair(pairs, lv.aoff[0] + g, b, other, ci0 | 0x80000000u, ci1 | 0x80000000u, o0 | 0x80000000u, o1 | 0x80000000u);
@@ -437,6 +449,51 @@ __global__ __launch_bounds__(256) void k_level(rt_bvh_info info, rt_aabb* __rest
     store_node(nodes, info.current_index + t, r, i1, i2);
 }
 
+// Private copy from a hierarchy in the reference's layout (for callers that trace without an accel): one
+// thread per sibling pair of every level below the trunk
+__global__ __launch_bounds__(256) void k_pairs_from_nodes(rt_levels lv, uint32_t total_pairs, const rt_aabb* __restrict__ nodes,
+                                                          rt_aabb* __restrict__ pairs) {
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= total_pairs) return;
+    uint32_t k = 0u;
+    for (; k + 1u < lv.count; k++) {
+        const uint32_t np = (lv.n[k] + 1u) / 2u;
+        if (t < np) break;
+        t -= np;
+    }
+    const uint32_t i = 2u * t;
+    const float4* a = reinterpret_cast<const float4*>(nodes + lv.off[k] + i);
+    const float4 alo = a[0], ahi = a[1];
+    Box ba, bb;
+    ba.mn[0] = alo.x; ba.mn[1] = alo.y; ba.mn[2] = alo.z; ba.mx[0] = alo.w; ba.mx[1] = ahi.x; ba.mx[2] = ahi.y;
+    uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu;
+    if (i + 1u < lv.n[k]) {
+        const float4 blo = a[2], bhi = a[3];
+        bb.mn[0] = blo.x; bb.mn[1] = blo.y; bb.mn[2] = blo.z; bb.mx[0] = blo.w; bb.mx[1] = bhi.x; bb.mx[2] = bhi.y;
+        b0 = __float_as_uint(bhi.z); b1 = __float_as_uint(bhi.w);
+    } else {
+        for (int c = 0; c < 3; c++) bb.mn[c] = bb.mx[c] = __uint_as_float(0x7fc00000u);
+    }
+    store_pair(pairs, lv.aoff[k] + i, ba, bb, __float_as_uint(ahi.z), __float_as_uint(ahi.w), b0, b1);
+}
+
+// ... and the Morton-ordered packed triangles from the leaves' links
+__global__ __launch_bounds__(256) void k_tris_from_leaves(uint32_t leaves, const rt_aabb* __restrict__ nodes,
+                                                          const uint32_t* __restrict__ indices, const rt_vertex* __restrict__ verts,
+                                                          float4* __restrict__ sorted_tris) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= leaves) return;
+    const uint32_t l0 = nodes[1u + g].link[0], l1 = nodes[1u + g].link[1];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const uint32_t link = (i < 3) ? l0 : l1;
+        if (link == 0xffffffffu) break;
+        const uint32_t ci = link & 0x7fffffffu;
+        const float* p = verts[indices[ci + (uint32_t)(i % 3)]].position;
+        sorted_tris[(size_t)g * 6u + (uint32_t)i] = make_float4(p[0], p[1], p[2], (i % 3 == 0) ? __uint_as_float(ci) : 0.0f);
+    }
+}
+
 inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 
 inline SceneBounds make_bounds(const float* mn, const float* mx) {
@@ -446,6 +503,18 @@ inline SceneBounds make_bounds(const float* mn, const float* mx) {
 }
 
 }  // namespace
+
+int rt_private_copy_from_reference(rt_device* dev, uint32_t num_prims, const rt_aabb* nodes, const uint32_t* indices,
+                                   const rt_vertex* verts, rt_aabb* pairs, float4* sorted_tris) {
+    rt_levels lv;
+    if (!rt_make_levels(num_prims, &lv)) return RT_ERR_TOO_FEW_PRIMITIVES;
+    uint32_t total_pairs = 0u;
+    for (uint32_t k = 0; k + 1u < lv.count; k++) total_pairs += (lv.n[k] + 1u) / 2u;
+    hipLaunchKernelGGL(k_pairs_from_nodes, dim3(div_up(total_pairs, 256u)), dim3(256), 0, dev->stream, lv, total_pairs, nodes, pairs);
+    hipLaunchKernelGGL(k_tris_from_leaves, dim3(div_up(lv.n[0], 256u)), dim3(256), 0, dev->stream, lv.n[0], nodes, indices, verts,
+                       sorted_tris);
+    return rt_launch_status();
+}
 
 int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted) {
     int rc = rt_sort_workspace(dev, n);

@@ -30,6 +30,12 @@ int rt_device_create(int gpu_index, rt_device** out) {
     d->queue_counter = nullptr;
     d->ray_keys_a = nullptr;
     d->ray_keys_b = nullptr;
+    d->conv_pairs = nullptr;
+    d->conv_tris = nullptr;
+    d->conv_capacity = 0;
+    d->time_traverse = false;
+    d->timing_events = nullptr;
+    d->timing_count = d->timing_capacity = 0;
     hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete d; return RT_ERR_HIP_BASE + (int)e; }
     e = hipMalloc((void**)&d->sort_totals, 512 * sizeof(uint32_t));
@@ -50,6 +56,10 @@ int rt_device_destroy(rt_device* dev) {
     if (dev->queue_counter) (void)hipFree(dev->queue_counter);
     if (dev->ray_keys_a) (void)hipFree(dev->ray_keys_a);
     if (dev->ray_keys_b) (void)hipFree(dev->ray_keys_b);
+    if (dev->conv_pairs) (void)hipFree(dev->conv_pairs);
+    if (dev->conv_tris) (void)hipFree(dev->conv_tris);
+    for (uint32_t i = 0; i < 2u * dev->timing_capacity; i++) (void)hipEventDestroy(dev->timing_events[i]);
+    delete[] dev->timing_events;
     if (dev->owns_stream && dev->stream) (void)hipStreamDestroy(dev->stream);
     delete dev;
     return RT_OK;

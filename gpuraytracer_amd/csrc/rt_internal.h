@@ -23,6 +23,14 @@ struct rt_device {
     uint32_t* queue_counter;   // ray queue heads of the persistent traversal kernel (256 bytes)
     uint2* ray_keys_a;         // [hit_capacity] (locality key, ray index) pairs: the order rays are handed out in
     uint2* ray_keys_b;
+    // private copy of the hierarchy for trace calls that come without an accel (rebuilt by every such call)
+    rt_aabb* conv_pairs;
+    float4* conv_tris;
+    uint32_t conv_capacity;    // primitives the two buffers are sized for
+    // optional event pairs around the traversal kernel (rt_device_set_traverse_timing)
+    bool time_traverse;
+    hipEvent_t* timing_events;      // [2 * timing_capacity]: start, stop, start, stop, ...
+    uint32_t timing_count, timing_capacity;
 };
 
 struct rt_buffer {
@@ -74,41 +82,44 @@ int rt_sort_workspace(rt_device* dev, uint32_t num_elements);   // grows dev->so
 // Stable LSD radix sort of (key, value) pairs by the low 8 * passes key bits, queued on the device's stream.
 // a and b hold n pairs each and are both overwritten; *sorted receives whichever of them holds the result.
 int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted);
+// Writes the private copy (interleaved sibling pairs, Morton-ordered packed triangles: see rt_levels and
+// rt_accel) of a hierarchy held in the reference's layout. pairs: rt_aligned_node_slots() slots;
+// sorted_tris: 6 float4 per leaf.
+int rt_private_copy_from_reference(rt_device* dev, uint32_t num_prims, const rt_aabb* nodes, const uint32_t* indices,
+                                   const rt_vertex* verts, rt_aabb* pairs, float4* sorted_tris);
 
 // level schedule of the balanced hierarchy (src/RaytracerPipeline.cpp:465-467, 497-559):
 // level 0 = leaves at node 1; level k has ceil(n_{k-1} / 2) nodes appended after level k-1;
 // the level holding a single node is the root and is stored at node 0.
 //
-// aoff is a second, private placement of the same nodes used by the accel's own copy: every level starts at
-// an even 32-byte slot, so the sibling pair (2j, 2j+1) of any level shares one 64-byte line (slots aoff + 2j and
-// aoff + 2j + 1), which holds the two boxes with their components interleaved.
+// aoff is a second, private placement of the same nodes used by the accel's own copy: node i of level k sits in
+// 32-byte slot 2^(root level - k) + i, the numbering of a complete binary tree (the node in slot h has its
+// children in slots 2h and 2h + 1; a level never holds more nodes than such a tree has room for). The two slots
+// 2h, 2h + 1 form one 64-byte record that holds both children's boxes with their components interleaved, so a
+// walk only needs h to find the record of a node's children. A child that does not exist (the last node of a
+// level with an odd count has one child) is stored as a box no ray can hit.
 struct rt_levels {
     uint32_t count;            // number of levels including the root level
     uint32_t n[33];            // nodes per level
     uint32_t off[33];          // first node index of each level (root level: 0)
-    uint32_t aoff[33];         // first slot of each level in the pair-aligned copy (root level: 0)
+    uint32_t aoff[33];         // first slot of each level in the private copy: 2^(count - 1 - k)
 };
 static inline bool rt_make_levels(uint32_t num_prims, rt_levels* lv) {
     if (num_prims < 3u) return false;
-    uint32_t n = (num_prims + 1u) / 2u, off = 1u, aoff = 2u, k = 0;
+    uint32_t n = (num_prims + 1u) / 2u, off = 1u, k = 0;
     for (;;) {
         lv->n[k] = n;
         lv->off[k] = (n == 1u) ? 0u : off;
-        lv->aoff[k] = (n == 1u) ? 0u : aoff;
         k++;
         if (n == 1u) break;
         off += n;
-        aoff += (n + 1u) & ~1u;
         n = (n + 1u) / 2u;
     }
     lv->count = k;
+    for (uint32_t j = 0; j < k; j++) lv->aoff[j] = 1u << (k - 1u - j);
     return true;
 }
-// slots the pair-aligned copy needs
-static inline size_t rt_aligned_node_slots(const rt_levels* lv) {
-    size_t slots = 2;
-    for (uint32_t k = 0; k + 1u < lv->count; k++) slots += (lv->n[k] + 1u) & ~1u;
-    return slots;
-}
+// 32-byte slots the private copy needs
+static inline size_t rt_aligned_node_slots(const rt_levels* lv) { return (size_t)2u << (lv->count - 1u); }
 
 #endif

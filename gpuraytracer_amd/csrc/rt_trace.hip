@@ -24,6 +24,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <new>
 
 #include "rt_internal.h"
 #include "rt_math.h"
@@ -358,33 +359,6 @@ __global__ __launch_bounds__(256) void k_trace(TraceParams p, ShadeBuffers b, co
 
 constexpr uint32_t kNoRay = 0xffffffffu;
 
-// Leaf of the wavefront kernel, identified by its index in level 0. PACKED takes the slot of each triangle's
-// first index from the w component of its first packed vertex; otherwise the links of the leaf's node.
-template <bool PACKED>
-__device__ __forceinline__ uint32_t test_leaf_by_index(f3 org, f3 dir, float tmin_r, float tmax_r, uint32_t leaf, uint32_t num_prims,
-                                                       uint32_t leaf_base, const float4* __restrict__ nodes,
-                                                       const uint32_t* __restrict__ indices, const rt_vertex* __restrict__ verts,
-                                                       const float4* __restrict__ sorted_tris, Hit& best, uint32_t& best_ci) {
-    if (PACKED) {
-        const float4* t = sorted_tris + 6 * (size_t)leaf;
-        const bool two = 2u * leaf + 1u < num_prims;
-        const float4 a0 = t[0], b0 = t[1], c0 = t[2];
-        float4 a1 = a0, b1 = b0, c1 = c0;
-        if (two) { a1 = t[3]; b1 = t[4]; c1 = t[5]; }
-        check_hit(intersect_tri(org, dir, mk(a0.x, a0.y, a0.z), mk(b0.x, b0.y, b0.z), mk(c0.x, c0.y, c0.z)), tmin_r, tmax_r,
-                  __float_as_uint(a0.w), best, best_ci);
-        if (two)
-            check_hit(intersect_tri(org, dir, mk(a1.x, a1.y, a1.z), mk(b1.x, b1.y, b1.z), mk(c1.x, c1.y, c1.z)), tmin_r, tmax_r,
-                      __float_as_uint(a1.w), best, best_ci);
-        return two ? 2u : 1u;
-    } else {
-        const float4 hi = nodes[2 * ((size_t)leaf_base + leaf) + 1];
-        const uint32_t l0 = __float_as_uint(hi.z), l1 = __float_as_uint(hi.w);
-        test_leaf<false>(org, dir, tmin_r, tmax_r, leaf, l0, l1, indices, verts, sorted_tris, best, best_ci);
-        return (l1 != 0xffffffffu) ? 2u : 1u;
-    }
-}
-
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // shader/CS_TraceRays.hlsl:81-97 for both boxes of an interleaved sibling pair at once (same operations per
@@ -406,50 +380,49 @@ __device__ __forceinline__ void slab_pair(f3 o, f3 inv_d, float tmin_r, float tm
 
 constexpr uint32_t kFifo = 8u;        // leaves a lane may have waiting for a triangle round
 
+// The walk runs on the private copy of the hierarchy: the node in slot h (trunk: 1) has the 64-byte record of
+// its two children at pairs[4h .. 4h + 3] and the children in slots 2h and 2h + 1; leaf i is slot
+// 2^root_level + i and owns triangles sorted_tris[6i .. 6i + 5].
+//
 // One step of a lane handles the two children of the node it has entered: both boxes are tested at once (the
 // reference tests the second one when its walk comes back to it, which it always does); of two children that
-// are hit, the walk goes into the first and notes the second's entry distance, to be compared with the closest
-// hit again when the walk returns. A lane that finds a leaf hit notes (leaf, entry distance) in a first-in
-// first-out list and walks on; once enough lanes of the wave have a leaf waiting, each of them tests its
-// oldest one, after comparing the noted distance with its closest hit again.
+// are hit, the walk goes into the first and notes the second (one bit per depth), which it enters when it
+// comes back. A lane that finds a leaf hit notes (leaf, entry distance) in a first-in first-out list and
+// walks on; once enough lanes of the wave have a leaf waiting, each of them tests its oldest one, after
+// comparing the noted distance with its closest hit again.
 //
 // This tests exactly the triangles of the reference's walk (shader/CS_TraceRays.hlsl:179-237), in its order:
 // box entry distances never decrease from a node to its descendants and the closest hit only shrinks, so a
 // leaf passes its delayed comparison exactly if it and all of its ancestors pass theirs in the reference's
 // walk, whose order of leaves (left child first) is the order of the list. Walking on with a closest hit that
-// is out of date only adds box tests. The counting variant walks only while no leaf is waiting, which makes
-// its box tests those of the reference's walk, too.
-//
-// PACKED: interleaved sibling pairs, Morton-ordered packed triangles; otherwise the reference's buffers.
-template <bool PACKED, bool STATS>
-__global__ __launch_bounds__(256) void k_traverse(TraceParams p, const uint32_t* __restrict__ indices,
-                                                  const rt_vertex* __restrict__ verts, const float4* __restrict__ rays,
-                                                  const float4* __restrict__ nodes, const float4* __restrict__ pairs,
-                                                  const float4* __restrict__ sorted_tris, float4* __restrict__ hit_records,
-                                                  uint32_t* __restrict__ hit_ci, uint32_t* __restrict__ queue,
-                                                  const uint2* __restrict__ order, unsigned long long* __restrict__ stats) {
+// is out of date, and entering a noted child without comparing its entry distance again as the reference
+// does, only adds box tests. The counting variant does compare again and walks only while no leaf is waiting,
+// which makes its box tests those of the reference's walk, too.
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* __restrict__ rays, const float4* __restrict__ nodes,
+                                                  const float4* __restrict__ pairs, const float4* __restrict__ sorted_tris,
+                                                  float4* __restrict__ hit_records, uint32_t* __restrict__ hit_ci,
+                                                  uint32_t* __restrict__ queue, const uint2* __restrict__ order,
+                                                  unsigned long long* __restrict__ stats) {
     extern __shared__ uint32_t s_dyn[];
-    __shared__ uint2 s_level[33];                  // (first slot, node count) of every level
-    if (threadIdx.x < 33u)
-        s_level[threadIdx.x] = make_uint2(PACKED ? p.lv.aoff[threadIdx.x] : p.lv.off[threadIdx.x], p.lv.n[threadIdx.x]);
-    __syncthreads();
-
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t root_level = p.lv.count - 1u;
-    float* s_far = reinterpret_cast<float*>(s_dyn);                          // [root_level][256] noted second children
-    uint2* s_fifo = reinterpret_cast<uint2*>(s_dyn + root_level * 256u);     // [kFifo][256] waiting leaves
+    const uint32_t first_leaf = 1u << root_level;              // slot of leaf 0
+    const uint32_t first_leaf_parent = first_leaf >> 1;        // nodes from this slot on have leaves as children
+    uint2* s_fifo = reinterpret_cast<uint2*>(s_dyn);                         // [kFifo][256] waiting leaves
+    float* s_far = reinterpret_cast<float*>(s_dyn + kFifo * 512u);           // [depth][256] counting variant only
     const float4 root_lo = nodes[0], root_hi = nodes[1];
 
     uint32_t ray = kNoRay;            // index of the ray this lane is walking
     bool exhausted = false;           // the queue had no ray left for this lane
     bool walk_done = false;           // the walk is over; waiting leaves may remain
-    bool popping = false;             // the subtree of (k, i) is finished: go to the nearest noted second child
+    bool popping = false;             // counting variant: the walk is on its way back to a noted child
     f3 org = mk(0.0f, 0.0f, 0.0f), dir = org, inv_d = org;
     float tmin_r = 0.0f, tmax_r = 0.0f;
     Hit best;
     best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
-    uint32_t best_ci = 0u, k = 0u, i = 0u;
-    uint32_t noted = 0u;              // bit j: the second child of the walk's ancestor at level j + 1 is noted in s_far[j]
+    uint32_t best_ci = 0u, h = 1u;
+    uint32_t noted = 0u;              // bit d: the second child at depth d of the walk's ancestor at depth d - 1 is noted
     uint32_t wait_head = 0u, wait_n = 0u;
     uint32_t n_nodes = 0u, n_tris = 0u, n_hits = 0u, n_rays = 0u;
     uint32_t q = blockIdx.x & 7u, queues_tried = 0u;       // wave-uniform
@@ -488,7 +461,7 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const uint32_t*
                         if (STATS) { n_nodes++; n_rays++; }
                         // the trunk is entered on any box hit
                         if (slab(org, inv_d, tmin_r, tmax_r, root_lo, root_hi) != 1e30f) {
-                            ray = rid; k = root_level; i = 0u;
+                            ray = rid; h = 1u;
                             walk_done = false; popping = false; noted = 0u;
                         } else {
                             hit_records[rid] = make_float4(best.t, 0.0f, 0.0f, 0.0f);
@@ -504,65 +477,55 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const uint32_t*
             continue;
         }
 
-        // 2. the two children of the entered node (k, i)
+        // 2. the two children of the entered node h
         const bool can_walk = ray != kNoRay && !walk_done && (STATS ? wait_n == 0u : wait_n + 2u <= kFifo);
-        if (can_walk && !popping) {
-            const uint32_t kc = k - 1u;
-            const uint2 level = s_level[kc];
-            const uint32_t c0 = 2u * i;
-            const bool valid1 = c0 + 1u < level.y;             // false: an only child
+        bool back = STATS && popping;                              // go back to the nearest noted child
+        if (can_walk && !back) {
+            const float4* rec = pairs + 4 * (size_t)h;
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
             float bt0, bt1;
-            if (PACKED) {
-                const float4* qp = pairs + 2 * ((size_t)level.x + c0);
-                slab_pair(org, inv_d, tmin_r, tmax_r, qp[0], qp[1], qp[2], bt0, bt1);
-            } else {
-                const float4* n0 = nodes + 2 * ((size_t)level.x + c0);
-                const float4* n1 = n0 + (valid1 ? 2 : 0);
-                bt0 = slab(org, inv_d, tmin_r, tmax_r, n0[0], n0[1]);
-                bt1 = slab(org, inv_d, tmin_r, tmax_r, n1[0], n1[1]);
-            }
+            slab_pair(org, inv_d, tmin_r, tmax_r, q0, q1, q2, bt0, bt1);
+            const bool valid1 = q0.y == q0.y;                      // a missing child is stored as NaNs
             if (STATS) n_nodes += valid1 ? 2u : 1u;
             const bool hit0 = (bt0 != 1e30f) && (bt0 < best.t);
             const bool hit1 = valid1 && (bt1 != 1e30f) && (bt1 < best.t);
-            if (kc == 0u) {                                     // the children are leaves
-                if (hit0) {
-                    s_fifo[((wait_head + wait_n) & (kFifo - 1u)) * 256u + tid] = make_uint2(c0, __float_as_uint(bt0));
-                    wait_n++;
-                }
-                if (hit1) {
-                    s_fifo[((wait_head + wait_n) & (kFifo - 1u)) * 256u + tid] = make_uint2(c0 + 1u, __float_as_uint(bt1));
-                    wait_n++;
-                }
-                popping = true;
-            } else {
-                if (hit0 && hit1) {
-                    s_far[kc * 256u + tid] = bt1;
-                    noted |= 1u << kc;
-                }
-                const bool go = hit0 || hit1;
-                i = go ? (c0 + (hit0 ? 0u : 1u)) : i;
-                k = go ? kc : k;
-                popping = !go;
+            const bool leaves = h >= first_leaf_parent;
+            const uint32_t child0 = 2u * h;
+            if (leaves && hit0) {
+                s_fifo[((wait_head + wait_n) & (kFifo - 1u)) * 256u + tid] = make_uint2(child0 - first_leaf, __float_as_uint(bt0));
+                wait_n++;
             }
+            if (leaves && hit1) {
+                s_fifo[((wait_head + wait_n) & (kFifo - 1u)) * 256u + tid] = make_uint2(child0 + 1u - first_leaf, __float_as_uint(bt1));
+                wait_n++;
+            }
+            const bool go = !leaves && (hit0 || hit1);
+            if (!leaves && hit0 && hit1) {
+                const uint32_t child_depth = 32u - (uint32_t)__builtin_clz(h);
+                noted |= 1u << child_depth;
+                if (STATS) s_far[child_depth * 256u + tid] = bt1;
+            }
+            h = go ? (child0 + (hit0 ? 0u : 1u)) : h;
+            back = !go;
         }
-
-        // 3. back to the nearest noted second child; it is entered if it still starts before the closest hit
-        //    (the counting variant first lets the leaves found in this step be tested)
-        if (can_walk && popping && (!STATS || wait_n == 0u)) {
+        //    ... or, once its subtree is finished, the nearest noted second child (the counting variant first
+        //    lets the leaves found in this step be tested, then compares the child's entry distance again)
+        if (can_walk && back && (!STATS || wait_n == 0u)) {
             if (!noted) {
                 walk_done = true;
                 popping = false;
             } else {
-                const uint32_t j = (uint32_t)__builtin_ctz(noted);
-                noted &= noted - 1u;
-                const float bt = s_far[j * 256u + tid];
-                i = (i >> (j - k)) | 1u;
-                k = j;
-                popping = !(bt < best.t);
+                const uint32_t d_to = 31u - (uint32_t)__builtin_clz(noted);
+                const uint32_t d_at = 31u - (uint32_t)__builtin_clz(h);
+                noted ^= 1u << d_to;
+                h = (h >> (d_at - d_to)) | 1u;
+                popping = STATS ? !(s_far[d_to * 256u + tid] < best.t) : false;
             }
+        } else if (STATS && can_walk) {
+            popping = back;
         }
 
-        // 4. triangle round once enough lanes have a leaf waiting (or nobody can walk any more)
+        // 3. triangle round once enough lanes have a leaf waiting (or nobody can walk any more)
         const unsigned long long waiting_mask = __builtin_amdgcn_ballot_w64(wait_n > 0u);
         if (waiting_mask) {
             const unsigned long long walking_mask =
@@ -573,15 +536,23 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const uint32_t*
                     wait_head = (wait_head + 1u) & (kFifo - 1u);
                     wait_n--;
                     if (__uint_as_float(e.y) < best.t) {
-                        const uint32_t tested = test_leaf_by_index<PACKED>(org, dir, tmin_r, tmax_r, e.x, p.num_prims, p.lv.off[0], nodes,
-                                                                           indices, verts, sorted_tris, best, best_ci);
-                        if (STATS) n_tris += tested;
+                        const float4* t = sorted_tris + 6 * (size_t)e.x;
+                        const bool two = 2u * e.x + 1u < p.num_prims;
+                        const float4 a0 = t[0], b0 = t[1], c0 = t[2];
+                        float4 a1 = a0, b1 = b0, c1 = c0;
+                        if (two) { a1 = t[3]; b1 = t[4]; c1 = t[5]; }
+                        check_hit(intersect_tri(org, dir, mk(a0.x, a0.y, a0.z), mk(b0.x, b0.y, b0.z), mk(c0.x, c0.y, c0.z)), tmin_r,
+                                  tmax_r, __float_as_uint(a0.w), best, best_ci);
+                        if (two)
+                            check_hit(intersect_tri(org, dir, mk(a1.x, a1.y, a1.z), mk(b1.x, b1.y, b1.z), mk(c1.x, c1.y, c1.z)), tmin_r,
+                                      tmax_r, __float_as_uint(a1.w), best, best_ci);
+                        if (STATS) n_tris += two ? 2u : 1u;
                     }
                 }
             }
         }
 
-        // 5. a finished ray leaves its closest hit behind and frees the lane
+        // 4. a finished ray leaves its closest hit behind and frees the lane
         if (ray != kNoRay && walk_done && wait_n == 0u) {
             hit_records[ray] = make_float4(best.t, best.u, best.v, best.w);
             hit_ci[ray] = best_ci;
@@ -646,6 +617,21 @@ int trace_workspace(rt_device* dev, uint32_t num_rays) {
     if (e == hipSuccess) e = hipMalloc((void**)&dev->ray_keys_b, (size_t)num_rays * 8u);
     if (e != hipSuccess) return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
     dev->hit_capacity = num_rays;
+    return RT_OK;
+}
+
+// buffers of the private hierarchy copy made for trace calls without an accel
+int convert_workspace(rt_device* dev, uint32_t num_prims, const rt_levels& lv) {
+    if (num_prims <= dev->conv_capacity) return RT_OK;
+    RT_HIP(hipStreamSynchronize(dev->stream));
+    if (dev->conv_pairs) { (void)hipFree(dev->conv_pairs); dev->conv_pairs = nullptr; }
+    if (dev->conv_tris) { (void)hipFree(dev->conv_tris); dev->conv_tris = nullptr; }
+    dev->conv_capacity = 0;
+    // both sizes grow with the primitive count
+    hipError_t e = hipMalloc((void**)&dev->conv_pairs, rt_aligned_node_slots(&lv) * sizeof(rt_aabb));
+    if (e == hipSuccess) e = hipMalloc((void**)&dev->conv_tris, (size_t)lv.n[0] * 6u * sizeof(float4));
+    if (e != hipSuccess) return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
+    dev->conv_capacity = num_prims;
     return RT_OK;
 }
 
@@ -745,16 +731,43 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         rc = rt_sort_pairs(dev, dev->ray_keys_a, dev->ray_keys_b, nr, 3u, &order);      // 24-bit keys
         if (rc) return rc;
     }
-    const size_t lds_bytes = ((size_t)(p.lv.count - 1u) * 256u + (size_t)kFifo * 512u) * sizeof(uint32_t);
-    const float4* pairs = accel ? (const float4*)accel->pairs : nullptr;
-#define RT_LAUNCH_TRAVERSE(PACKED, STATS)                                                                                       \
-    hipLaunchKernelGGL((k_traverse<PACKED, STATS>), dim3(groups), block, lds_bytes, s, p, b.indices, b.verts, ray_in, nodes, pairs, \
-                       st, dev->hit_records, dev->hit_ci, dev->queue_counter, order, stats)
-    if (accel && stats) RT_LAUNCH_TRAVERSE(true, true);
-    else if (accel) RT_LAUNCH_TRAVERSE(true, false);
-    else if (stats) RT_LAUNCH_TRAVERSE(false, true);
-    else RT_LAUNCH_TRAVERSE(false, false);
+    // the walk runs on the private copy of the hierarchy; a call without an accel gets one made from its buffers
+    const float4* pairs = nullptr;
+    if (accel) {
+        pairs = (const float4*)accel->pairs;
+    } else {
+        rc = convert_workspace(dev, p.num_prims, p.lv);
+        if (rc) return rc;
+        rc = rt_private_copy_from_reference(dev, p.num_prims, (const rt_aabb*)bvh->ptr, b.indices, b.verts, dev->conv_pairs,
+                                            dev->conv_tris);
+        if (rc) return rc;
+        pairs = (const float4*)dev->conv_pairs;
+        st = (const float4*)dev->conv_tris;
+    }
+    // waiting leaves; the counting variant also keeps the entry distances of noted children, one row per depth
+    const size_t lds_bytes = ((size_t)kFifo * 512u + (stats ? (size_t)p.lv.count * 256u : 0u)) * sizeof(uint32_t);
+#define RT_LAUNCH_TRAVERSE(STATS)                                                                                             \
+    hipLaunchKernelGGL((k_traverse<STATS>), dim3(groups), block, lds_bytes, s, p, ray_in, nodes, pairs, st, dev->hit_records, \
+                       dev->hit_ci, dev->queue_counter, order, stats)
+    hipEvent_t* timing = nullptr;
+    if (dev->time_traverse) {
+        if (dev->timing_count == dev->timing_capacity) {      // grow the pool of event pairs
+            const uint32_t cap = dev->timing_capacity ? 2u * dev->timing_capacity : 64u;
+            hipEvent_t* ev = new (std::nothrow) hipEvent_t[2u * cap];
+            if (!ev) return RT_ERR_OUT_OF_MEMORY;
+            for (uint32_t e = 0; e < 2u * dev->timing_capacity; e++) ev[e] = dev->timing_events[e];
+            for (uint32_t e = 2u * dev->timing_capacity; e < 2u * cap; e++) RT_HIP(hipEventCreate(&ev[e]));
+            delete[] dev->timing_events;
+            dev->timing_events = ev;
+            dev->timing_capacity = cap;
+        }
+        timing = dev->timing_events + 2u * dev->timing_count++;
+        RT_HIP(hipEventRecord(timing[0], s));
+    }
+    if (stats) RT_LAUNCH_TRAVERSE(true);
+    else RT_LAUNCH_TRAVERSE(false);
 #undef RT_LAUNCH_TRAVERSE
+    if (timing) RT_HIP(hipEventRecord(timing[1], s));
     rc = rt_launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(k_shade, grid, block, 0, s, p, b, (const float4*)dev->hit_records, (const uint32_t*)dev->hit_ci);
@@ -768,6 +781,30 @@ extern "C" {
 int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats) {
     if (!dev || (stats && stats->bytes < 32u)) return RT_ERR_INVALID_ARGUMENT;
     dev->trace_stats = stats ? (unsigned long long*)stats->ptr : nullptr;
+    return RT_OK;
+}
+
+int rt_device_set_traverse_timing(rt_device* dev, int enable) {
+    if (!dev) return RT_ERR_INVALID_ARGUMENT;
+    dev->time_traverse = enable != 0;
+    dev->timing_count = 0;
+    return RT_OK;
+}
+
+int rt_device_traverse_timing(rt_device* dev, double* total_ms, uint32_t* launches) {
+    if (!dev || !total_ms || !launches) return RT_ERR_INVALID_ARGUMENT;
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+    double sum = 0.0;
+    for (uint32_t e = 0; e < dev->timing_count; e++) {
+        float ms = 0.0f;
+        RT_HIP(hipEventSynchronize(dev->timing_events[2u * e + 1u]));
+        RT_HIP(hipEventElapsedTime(&ms, dev->timing_events[2u * e], dev->timing_events[2u * e + 1u]));
+        sum += (double)ms;
+    }
+    *total_ms = sum;
+    *launches = dev->timing_count;
+    dev->timing_count = 0;
     return RT_OK;
 }
 

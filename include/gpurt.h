@@ -78,6 +78,11 @@ const char* rt_error_string(int code);
  * {box tests, triangle tests, rays that hit, rays} as four uint64 to it (a slower kernel variant); NULL turns
  * it off. The counts fix the algorithmic bytes per ray of a workload. */
 int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats);
+/* Instrumentation (no counterpart in the reference): while enabled, every trace launch brackets its traversal
+ * kernel with a pair of events on the device's stream. rt_device_traverse_timing waits for the pairs recorded
+ * so far, returns the sum of their durations and their number, and forgets them. */
+int rt_device_set_traverse_timing(rt_device* dev, int enable);
+int rt_device_traverse_timing(rt_device* dev, double* total_ms, uint32_t* launches);
 
 int rt_event_create(rt_device* dev, rt_event** out);
 int rt_event_record(rt_event* ev);                       /* on the device's stream */
