@@ -286,6 +286,19 @@ __device__ __forceinline__ void store_node(rt_aabb* nodes, uint32_t idx, const B
     p[1] = make_float4(b.mx[1], b.mx[2], __uint_as_float(l0), __uint_as_float(l1));
 }
 
+// The two triangles of a leaf, interleaved for the packed two-triangle test (80 bytes):
+//   (a0.x a1.x a0.y a1.y) (a0.z a1.z b0.x b1.x) (b0.y b1.y b0.z b1.z) (c0.x c1.x c0.y c1.y) (c0.z c1.z ci0 ci1)
+// p[0..2] = corners of triangle 0, p[3..5] of triangle 1 (a copy of triangle 0, ci1 = 0xffffffff, if there is none)
+__device__ __forceinline__ void store_leaf_triangles(float4* sorted_tris, uint32_t leaf, const float (*p)[3], uint32_t ci0,
+                                                     uint32_t ci1) {
+    float4* o = sorted_tris + 5 * (size_t)leaf;
+    o[0] = make_float4(p[0][0], p[3][0], p[0][1], p[3][1]);
+    o[1] = make_float4(p[0][2], p[3][2], p[1][0], p[4][0]);
+    o[2] = make_float4(p[1][1], p[4][1], p[1][2], p[4][2]);
+    o[3] = make_float4(p[2][0], p[5][0], p[2][1], p[5][1]);
+    o[4] = make_float4(p[2][2], p[5][2], __uint_as_float(ci0), __uint_as_float(ci1));
+}
+
 // The accel's private copy of the hierarchy holds sibling pairs: children 2j and 2j+1 of every node share one
 // 64-byte line, components interleaved so that one packed operation covers both boxes:
 //   (min.x0, min.x1, min.y0, min.y1) (min.z0, min.z1, max.x0, max.x1) (max.y0, max.y1, max.z0, max.z1) (links0, links1)
@@ -390,23 +403,27 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
         ci0 = sorted[(size_t)(2u * g) * STRIDE + 1];
         const bool two = (2u * g + 1u) < num_prims;
         if (two) ci1 = sorted[(size_t)(2u * g + 1u) * STRIDE + 1];
+        float corner[6][3];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            if (i >= 3 && !two) break;
+            if (i >= 3 && !two) {                       // no second triangle: repeat the first
+                corner[i][0] = corner[i - 3][0]; corner[i][1] = corner[i - 3][1]; corner[i][2] = corner[i - 3][2];
+                continue;
+            }
             const uint32_t ci = (i < 3) ? ci0 : ci1;
             float px, py, pz;
             if (PACKED) {
-                float4 p = tris[ci + (uint32_t)(i % 3)];
+                const float4 p = tris[ci + (uint32_t)(i % 3)];
                 px = p.x; py = p.y; pz = p.z;
-                if (i % 3 == 0) p.w = __uint_as_float(ci);
-                sorted_tris[(size_t)(2u * g) * 3u + (uint32_t)i] = p;
             } else {
                 const float* p = verts[indices[ci + (uint32_t)(i % 3)]].position;
                 px = p[0]; py = p[1]; pz = p[2];
             }
+            corner[i][0] = px; corner[i][1] = py; corner[i][2] = pz;
             b.mn[0] = fminf(b.mn[0], px); b.mn[1] = fminf(b.mn[1], py); b.mn[2] = fminf(b.mn[2], pz);
             b.mx[0] = fmaxf(b.mx[0], px); b.mx[1] = fmaxf(b.mx[1], py); b.mx[2] = fmaxf(b.mx[2], pz);
         }
+        if (PACKED) store_leaf_triangles(sorted_tris, g, corner, ci0, ci1);
         store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
     }
     if (PACKED && pairs) {                             // same for the whole grid
@@ -484,14 +501,15 @@ __global__ __launch_bounds__(256) void k_tris_from_leaves(uint32_t leaves, const
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     if (g >= leaves) return;
     const uint32_t l0 = nodes[1u + g].link[0], l1 = nodes[1u + g].link[1];
+    float corner[6][3];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        const uint32_t link = (i < 3) ? l0 : l1;
-        if (link == 0xffffffffu) break;
+        const uint32_t link = (i < 3 || l1 == 0xffffffffu) ? l0 : l1;
         const uint32_t ci = link & 0x7fffffffu;
         const float* p = verts[indices[ci + (uint32_t)(i % 3)]].position;
-        sorted_tris[(size_t)g * 6u + (uint32_t)i] = make_float4(p[0], p[1], p[2], (i % 3 == 0) ? __uint_as_float(ci) : 0.0f);
+        corner[i][0] = p[0]; corner[i][1] = p[1]; corner[i][2] = p[2];
     }
+    store_leaf_triangles(sorted_tris, g, corner, l0 & 0x7fffffffu, l1 == 0xffffffffu ? l1 : (l1 & 0x7fffffffu));
 }
 
 inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
@@ -666,7 +684,7 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
     a->pairs = nullptr;
     const size_t tri_bytes = (size_t)max_primitives * 48u, key_bytes = (size_t)max_primitives * 8u;
     hipError_t e = hipMalloc((void**)&a->tris, tri_bytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&a->sorted_tris, tri_bytes + 48u);   // odd counts pad the last leaf
+    if (e == hipSuccess) e = hipMalloc((void**)&a->sorted_tris, ((size_t)max_primitives + 1u) / 2u * 80u);   // 80 bytes per leaf
     if (e == hipSuccess) e = hipMalloc((void**)&a->keys_a, key_bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&a->keys_b, key_bytes);
     {

@@ -50,7 +50,7 @@ struct rt_accel {
     uint32_t max_prims;
     uint32_t num_prims;        // set by rt_accel_pack
     float4* tris;              // [3*max_prims] packed positions, original order
-    float4* sorted_tris;       // [3*max_prims] packed positions, Morton order (w of vertex 0 = 3*tri)
+    float4* sorted_tris;       // [5 * leaves] the two triangles of every leaf in Morton order, interleaved (80 bytes)
     rt_aabb* pairs;            // private copy of the hierarchy as interleaved sibling pairs (rt_levels::aoff placement)
     uint2* keys_a;             // [max_prims] (code, 3*tri)
     uint2* keys_b;             // [max_prims]
@@ -84,7 +84,7 @@ int rt_sort_workspace(rt_device* dev, uint32_t num_elements);   // grows dev->so
 int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted);
 // Writes the private copy (interleaved sibling pairs, Morton-ordered packed triangles: see rt_levels and
 // rt_accel) of a hierarchy held in the reference's layout. pairs: rt_aligned_node_slots() slots;
-// sorted_tris: 6 float4 per leaf.
+// sorted_tris: 5 float4 per leaf.
 int rt_private_copy_from_reference(rt_device* dev, uint32_t num_prims, const rt_aabb* nodes, const uint32_t* indices,
                                    const rt_vertex* verts, rt_aabb* pairs, float4* sorted_tris);
 

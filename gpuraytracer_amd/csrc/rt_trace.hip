@@ -256,32 +256,17 @@ __device__ __forceinline__ void add_stats(unsigned long long* stats, unsigned lo
     }
 }
 
-// leaf triangles: PACKED reads the Morton-ordered float4 x 3 array (leaf i holds sorted triangles 2i, 2i+1),
-// otherwise Indices -> Vertices through the leaf's links
-template <bool PACKED>
-__device__ __forceinline__ void test_leaf(f3 org, f3 dir, float tmin_r, float tmax_r, uint32_t leaf, uint32_t l0, uint32_t l1,
-                                          const uint32_t* __restrict__ indices, const rt_vertex* __restrict__ verts,
-                                          const float4* __restrict__ sorted_tris, Hit& best, uint32_t& best_ci) {
+// leaf triangles through the leaf's links: Indices -> Vertices (shader/CS_TraceRays.hlsl:196-214)
+__device__ __forceinline__ void test_leaf(f3 org, f3 dir, float tmin_r, float tmax_r, uint32_t l0, uint32_t l1,
+                                          const uint32_t* __restrict__ indices, const rt_vertex* __restrict__ verts, Hit& best,
+                                          uint32_t& best_ci) {
     const uint32_t ci0 = l0 & 0x7fffffffu;
-    f3 a, b, c;
-    if (PACKED) {
-        const float4* t = sorted_tris + 6 * (size_t)leaf;
-        float4 ta = t[0], tb = t[1], tc = t[2];
-        a = mk(ta.x, ta.y, ta.z); b = mk(tb.x, tb.y, tb.z); c = mk(tc.x, tc.y, tc.z);
-    } else {
-        a = vpos(verts, indices[ci0]); b = vpos(verts, indices[ci0 + 1]); c = vpos(verts, indices[ci0 + 2]);
-    }
-    check_hit(intersect_tri(org, dir, a, b, c), tmin_r, tmax_r, ci0, best, best_ci);
+    check_hit(intersect_tri(org, dir, vpos(verts, indices[ci0]), vpos(verts, indices[ci0 + 1]), vpos(verts, indices[ci0 + 2])), tmin_r,
+              tmax_r, ci0, best, best_ci);
     if (l1 != 0xffffffffu) {
         const uint32_t ci1 = l1 & 0x7fffffffu;
-        if (PACKED) {
-            const float4* t = sorted_tris + 6 * (size_t)leaf + 3;
-            float4 ta = t[0], tb = t[1], tc = t[2];
-            a = mk(ta.x, ta.y, ta.z); b = mk(tb.x, tb.y, tb.z); c = mk(tc.x, tc.y, tc.z);
-        } else {
-            a = vpos(verts, indices[ci1]); b = vpos(verts, indices[ci1 + 1]); c = vpos(verts, indices[ci1 + 2]);
-        }
-        check_hit(intersect_tri(org, dir, a, b, c), tmin_r, tmax_r, ci1, best, best_ci);
+        check_hit(intersect_tri(org, dir, vpos(verts, indices[ci1]), vpos(verts, indices[ci1 + 1]), vpos(verts, indices[ci1 + 2])),
+                  tmin_r, tmax_r, ci1, best, best_ci);
     }
 }
 
@@ -298,9 +283,9 @@ __device__ __forceinline__ bool pop_node(uint32_t& k, uint32_t& i, uint32_t root
 }
 
 // ---- simple form: one thread per ray through traversal and shading (also the RT_USE_BVH = 0 path) ----
-template <bool USE_BVH, bool PACKED, bool STATS>
+template <bool USE_BVH, bool STATS>
 __global__ __launch_bounds__(256) void k_trace(TraceParams p, ShadeBuffers b, const float4* __restrict__ nodes,
-                                               const float4* __restrict__ sorted_tris, unsigned long long* __restrict__ stats) {
+                                               unsigned long long* __restrict__ stats) {
     __shared__ uint32_t s_off[33];
     __shared__ uint32_t s_n[33];
     if (USE_BVH) {
@@ -343,7 +328,7 @@ __global__ __launch_bounds__(256) void k_trace(TraceParams p, ShadeBuffers b, co
                     if (enter && k > 0u) { k--; i <<= 1; continue; }
                     if (enter) {
                         const uint32_t l0 = __float_as_uint(hi.z), l1 = __float_as_uint(hi.w);
-                        test_leaf<PACKED>(org, dir, tmin_r, tmax_r, i, l0, l1, b.indices, b.verts, sorted_tris, best, best_ci);
+                        test_leaf(org, dir, tmin_r, tmax_r, l0, l1, b.indices, b.verts, best, best_ci);
                         if (STATS) n_tris += (l1 != 0xffffffffu) ? 2u : 1u;
                     }
                 }
@@ -380,9 +365,40 @@ __device__ __forceinline__ void slab_pair(f3 o, f3 inv_d, float tmin_r, float tm
 
 constexpr uint32_t kFifo = 8u;        // leaves a lane may have waiting for a triangle round
 
+// shader/CS_TraceRays.hlsl:46-77 for the two triangles of a leaf at once: every quantity is a pair (triangle 0,
+// triangle 1) and every operation of intersect_tri() is applied to both halves by one packed instruction
+// where the hardware has one. The leaf is held interleaved, 80 bytes:
+//   (a0.x a1.x a0.y a1.y) (a0.z a1.z b0.x b1.x) (b0.y b1.y b0.z b1.z) (c0.x c1.x c0.y c1.y) (c0.z c1.z ci0 ci1)
+// with a, b, c the corners, ci the slot of the triangle's first index; ci1 = 0xffffffff marks a leaf that
+// holds one triangle (its second half repeats the first).
+__device__ __forceinline__ void intersect_leaf(f3 o, f3 d, float4 l0, float4 l1, float4 l2, float4 l3, float4 l4, Hit& h0, Hit& h1) {
+    const v2f ax = {l0.x, l0.y}, ay = {l0.z, l0.w}, az = {l1.x, l1.y};
+    const v2f bx = {l1.z, l1.w}, by = {l2.x, l2.y}, bz = {l2.z, l2.w};
+    const v2f cx = {l3.x, l3.y}, cy = {l3.z, l3.w}, cz = {l4.x, l4.y};
+    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const v2f dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z};
+    const v2f e1x = bx - ax, e1y = by - ay, e1z = bz - az;
+    const v2f e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
+    const v2f tx = ox - ax, ty = oy - ay, tz = oz - az;
+    const v2f px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;       // cross(d, e2)
+    const v2f qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;       // cross(tv, e1)
+    const v2f det = (e1x * px + e1y * py) + e1z * pz;
+    const v2f inv = {(fabsf(det.x) < 1e-6f) ? 0.0f : 1.0f / det.x, (fabsf(det.y) < 1e-6f) ? 0.0f : 1.0f / det.y};
+    const v2f t = ((e2x * qx + e2y * qy) + e2z * qz) * inv;
+    const v2f u = ((tx * px + ty * py) + tz * pz) * inv;
+    const v2f v = ((dx * qx + dy * qy) + dz * qz) * inv;
+    const v2f uv = u + v;
+    h0.w = rintf(fabsf(det.x) * inv.x);
+    h1.w = rintf(fabsf(det.y) * inv.y);
+    if (t.x < 1e-6f || u.x < 0.0f || v.x < 0.0f || uv.x > 1.0f) { h0.t = -1.0f; h0.u = -1.0f; h0.v = -1.0f; }
+    else { h0.t = t.x; h0.u = u.x; h0.v = v.x; }
+    if (t.y < 1e-6f || u.y < 0.0f || v.y < 0.0f || uv.y > 1.0f) { h1.t = -1.0f; h1.u = -1.0f; h1.v = -1.0f; }
+    else { h1.t = t.y; h1.u = u.y; h1.v = v.y; }
+}
+
 // The walk runs on the private copy of the hierarchy: the node in slot h (trunk: 1) has the 64-byte record of
 // its two children at pairs[4h .. 4h + 3] and the children in slots 2h and 2h + 1; leaf i is slot
-// 2^root_level + i and owns triangles sorted_tris[6i .. 6i + 5].
+// 2^root_level + i and owns the interleaved triangle pair sorted_tris[5i .. 5i + 4].
 //
 // One step of a lane handles the two children of the node it has entered: both boxes are tested at once (the
 // reference tests the second one when its walk comes back to it, which it always does); of two children that
@@ -536,16 +552,14 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
                     wait_head = (wait_head + 1u) & (kFifo - 1u);
                     wait_n--;
                     if (__uint_as_float(e.y) < best.t) {
-                        const float4* t = sorted_tris + 6 * (size_t)e.x;
-                        const bool two = 2u * e.x + 1u < p.num_prims;
-                        const float4 a0 = t[0], b0 = t[1], c0 = t[2];
-                        float4 a1 = a0, b1 = b0, c1 = c0;
-                        if (two) { a1 = t[3]; b1 = t[4]; c1 = t[5]; }
-                        check_hit(intersect_tri(org, dir, mk(a0.x, a0.y, a0.z), mk(b0.x, b0.y, b0.z), mk(c0.x, c0.y, c0.z)), tmin_r,
-                                  tmax_r, __float_as_uint(a0.w), best, best_ci);
-                        if (two)
-                            check_hit(intersect_tri(org, dir, mk(a1.x, a1.y, a1.z), mk(b1.x, b1.y, b1.z), mk(c1.x, c1.y, c1.z)), tmin_r,
-                                      tmax_r, __float_as_uint(a1.w), best, best_ci);
+                        const float4* t = sorted_tris + 5 * (size_t)e.x;
+                        const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
+                        const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
+                        const bool two = ci1 != 0xffffffffu;
+                        Hit h0, h1;
+                        intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
+                        check_hit(h0, tmin_r, tmax_r, ci0, best, best_ci);
+                        if (two) check_hit(h1, tmin_r, tmax_r, ci1, best, best_ci);
                         if (STATS) n_tris += two ? 2u : 1u;
                     }
                 }
@@ -629,7 +643,7 @@ int convert_workspace(rt_device* dev, uint32_t num_prims, const rt_levels& lv) {
     dev->conv_capacity = 0;
     // both sizes grow with the primitive count
     hipError_t e = hipMalloc((void**)&dev->conv_pairs, rt_aligned_node_slots(&lv) * sizeof(rt_aabb));
-    if (e == hipSuccess) e = hipMalloc((void**)&dev->conv_tris, (size_t)lv.n[0] * 6u * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&dev->conv_tris, (size_t)lv.n[0] * 5u * sizeof(float4));
     if (e != hipSuccess) return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
     dev->conv_capacity = num_prims;
     return RT_OK;
@@ -703,15 +717,13 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     hipStream_t s = dev->stream;
 
     if (!use_bvh) {
-        if (stats) hipLaunchKernelGGL((k_trace<false, false, true>), grid, block, 0, s, p, b, nodes, st, stats);
-        else hipLaunchKernelGGL((k_trace<false, false, false>), grid, block, 0, s, p, b, nodes, st, stats);
+        if (stats) hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, s, p, b, nodes, stats);
+        else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, s, p, b, nodes, stats);
         return rt_launch_status();
     }
     if (simple_kernel) {
-        if (accel && stats) hipLaunchKernelGGL((k_trace<true, true, true>), grid, block, 0, s, p, b, nodes, st, stats);
-        else if (accel) hipLaunchKernelGGL((k_trace<true, true, false>), grid, block, 0, s, p, b, nodes, st, stats);
-        else if (stats) hipLaunchKernelGGL((k_trace<true, false, true>), grid, block, 0, s, p, b, nodes, st, stats);
-        else hipLaunchKernelGGL((k_trace<true, false, false>), grid, block, 0, s, p, b, nodes, st, stats);
+        if (stats) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, s, p, b, nodes, stats);
+        else hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, s, p, b, nodes, stats);
         return rt_launch_status();
     }
 
