@@ -42,7 +42,7 @@ struct TraceParams {
     uint32_t num_prims;
     uint32_t num_materials, num_textures;
     uint32_t leaf_threshold;
-    uint32_t queue_chunk;      // rays per queue of the persistent traversal kernel (a multiple of 64)
+    uint32_t queue_chunk;      // slots per queue of the persistent traversal kernel (a multiple of 64)
     rt_levels lv;
 };
 
@@ -445,9 +445,9 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
 
     for (;;) {
         // 1. refill: every lane without a ray takes the next index; one atomic per wave.
-        //    Eight queues, each over a contiguous eighth of the rays. Workgroups b and b + 8 are dealt to the same
-        //    XCD, so the waves that share an L2 start on the same queue, i.e. on the same image region; a wave
-        //    whose queue has run dry moves on to the next one (a speed choice only: any wave may take any ray).
+        //    Eight queues, each over an eighth of the rays. Workgroups b and b + 8 are dealt to the same XCD, so
+        //    the waves that share an L2 start on the same queue; a wave whose queue has run dry moves on to the
+        //    next one (a speed choice only: any wave may take any ray).
         const bool need = (ray == kNoRay) && !exhausted;
         const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(need);
         if (need_mask) {
@@ -455,19 +455,24 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
                 exhausted = exhausted || need;             // every queue has been seen empty
             } else {
                 const uint32_t q_begin = q * p.queue_chunk;
-                const uint32_t q_end = min(q_begin + p.queue_chunk, p.num_rays);
+                const uint32_t q_end = q_begin + p.queue_chunk;
                 const uint32_t leader = (uint32_t)__builtin_ctzll(need_mask);
                 uint32_t base = 0u;
                 if (lane == leader) base = atomicAdd(queue + 8u * q, (uint32_t)__popcll(need_mask));
                 base = q_begin + (uint32_t)__shfl((int)base, (int)leader, 64);
-                if (base >= q_end || q_begin >= p.num_rays) {      // wave-uniform: this queue is empty
+                if (base >= q_end) {                               // wave-uniform: this queue is empty
                     q = (q + 1u) & 7u;
                     queues_tried++;
                 } else if (need) {
                     const uint32_t mine = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
                                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
                     if (mine < q_end) {                    // lanes past the end stay hungry and try the next queue
-                        const uint32_t rid = order ? order[mine].y : mine;     // queue position -> ray
+                        // queue position -> position in the ray order (blocks of 64 positions are dealt to the eight
+                        // queues in turn, so that every queue starts with long walks) -> ray
+                        const uint32_t slot = mine - q_begin;
+                        const uint32_t pos = (((slot >> 6) * 8u + q) << 6) | (slot & 63u);
+                        if (pos < p.num_rays) {                // the last block may be short: such a lane asks again
+                        const uint32_t rid = order ? order[pos].y : pos;
                         const float4 r0 = rays[2 * (size_t)rid], r1 = rays[2 * (size_t)rid + 1];
                         org = mk(r0.x, r0.y, r0.z); dir = mk(r0.w, r1.x, r1.y);
                         tmin_r = r1.z; tmax_r = r1.w;
@@ -482,6 +487,7 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
                         } else {
                             hit_records[rid] = make_float4(best.t, 0.0f, 0.0f, 0.0f);
                             hit_ci[rid] = 0u;
+                        }
                         }
                     }
                 }
@@ -577,32 +583,50 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
     if (STATS) add_stats(stats, n_nodes, n_tris, n_hits, n_rays);
 }
 
-// Locality key of every ray for the order the traversal queues hand rays out in (the reference has no such
-// step; the order rays are traced in does not enter any result). Rays that start in the same cell of a
-// 32^3 grid over the trunk's box and point into the same of 8^3 direction cells get neighbouring queue
-// positions, so the lanes of a wave, and the waves of an XCD, walk the same part of the hierarchy.
-__device__ __forceinline__ uint32_t spread3(uint32_t v) {      // abcde -> a00b00c00d00e
+// Key of every ray for the order the traversal queues hand rays out in (the reference has no such step; the
+// order rays are traced in does not enter any result).
+//  * Major part, descending: an estimate of the walk's length - how many of the nodes at one depth near the
+//    trunk the ray's segment touches. Walk lengths are spread over three orders of magnitude, and a launch ends
+//    with its longest walks; handing those out first keeps all lanes busy to the end.
+//  * Minor part: locality - rays that start in the same cell of a 16^3 grid over the trunk's box and point
+//    into the same of 4^3 direction cells get neighbouring queue positions.
+// first_record / num_records: the records (pairs of boxes) of the nodes at the probing depth, which every
+// lane reads in the same order (uniform addresses).
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {      // abcd -> a00b00c00d
     v = (v | (v << 8)) & 0x0000f00fu;
     v = (v | (v << 4)) & 0x000c30c3u;
     v = (v | (v << 2)) & 0x00249249u;
     return v;
 }
 __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float4* __restrict__ rays,
-                                                  const float4* __restrict__ nodes, uint2* __restrict__ keys) {
+                                                  const float4* __restrict__ nodes, const float4* __restrict__ pairs,
+                                                  uint32_t first_record, uint32_t num_records, uint32_t cost_shift,
+                                                  uint2* __restrict__ keys) {
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     if (tid >= num_rays) return;
     const float4 lo = nodes[0], hi = nodes[1];
     const float4 r0 = rays[2 * (size_t)tid], r1 = rays[2 * (size_t)tid + 1];
+    const f3 org = mk(r0.x, r0.y, r0.z), dir = mk(r0.w, r1.x, r1.y);
+    const f3 inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    uint32_t touched = 0u;
+    for (uint32_t j = 0u; j < num_records; j++) {
+        const float4* rec = pairs + 4 * (size_t)(first_record + j);
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+        float bt0, bt1;
+        slab_pair(org, inv_d, r1.z, r1.w, q0, q1, q2, bt0, bt1);
+        touched += (bt0 != 1e30f ? 1u : 0u) + ((q0.y == q0.y) && (bt1 != 1e30f) ? 1u : 0u);
+    }
+    const uint32_t cost_class = min(touched >> cost_shift, 63u);
     const float cx = (r0.x - lo.x) / (lo.w - lo.x), cy = (r0.y - lo.y) / (hi.x - lo.y), cz = (r0.z - lo.z) / (hi.y - lo.z);
-    const uint32_t ox = (uint32_t)fminf(fmaxf(cx * 32.0f, 0.0f), 31.0f);
-    const uint32_t oy = (uint32_t)fminf(fmaxf(cy * 32.0f, 0.0f), 31.0f);
-    const uint32_t oz = (uint32_t)fminf(fmaxf(cz * 32.0f, 0.0f), 31.0f);
-    const uint32_t dx = (uint32_t)fminf(fmaxf(r0.w * 4.0f + 4.0f, 0.0f), 7.0f);
-    const uint32_t dy = (uint32_t)fminf(fmaxf(r1.x * 4.0f + 4.0f, 0.0f), 7.0f);
-    const uint32_t dz = (uint32_t)fminf(fmaxf(r1.y * 4.0f + 4.0f, 0.0f), 7.0f);
-    const uint32_t okey = spread3(ox) | (spread3(oy) << 1) | (spread3(oz) << 2);
-    const uint32_t dkey = spread3(dx) | (spread3(dy) << 1) | (spread3(dz) << 2);
-    keys[tid] = make_uint2((okey << 9) | dkey, tid);
+    const uint32_t ox = (uint32_t)fminf(fmaxf(cx * 16.0f, 0.0f), 15.0f);
+    const uint32_t oy = (uint32_t)fminf(fmaxf(cy * 16.0f, 0.0f), 15.0f);
+    const uint32_t oz = (uint32_t)fminf(fmaxf(cz * 16.0f, 0.0f), 15.0f);
+    const uint32_t dx = (uint32_t)fminf(fmaxf(r0.w * 2.0f + 2.0f, 0.0f), 3.0f);
+    const uint32_t dy = (uint32_t)fminf(fmaxf(r1.x * 2.0f + 2.0f, 0.0f), 3.0f);
+    const uint32_t dz = (uint32_t)fminf(fmaxf(r1.y * 2.0f + 2.0f, 0.0f), 3.0f);
+    const uint32_t okey = spread3(ox) | (spread3(oy) << 1) | (spread3(oz) << 2);      // 12 bits
+    const uint32_t dkey = spread3(dx) | (spread3(dy) << 1) | (spread3(dz) << 2);      // 6 bits
+    keys[tid] = make_uint2(((63u - cost_class) << 18) | (okey << 6) | dkey, tid);
 }
 
 __global__ __launch_bounds__(256) void k_shade(TraceParams p, ShadeBuffers b, const float4* __restrict__ hit_records,
@@ -677,7 +701,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
 
     // tuning knobs (read once): GPURT_TRACE_KERNEL=simple selects the one-thread-per-ray kernel
     static const bool simple_kernel = [] { const char* v = std::getenv("GPURT_TRACE_KERNEL"); return v && !std::strcmp(v, "simple"); }();
-    static const uint32_t leaf_threshold = env_u32("GPURT_LEAF_THRESHOLD", 16u);
+    static const uint32_t leaf_threshold = env_u32("GPURT_LEAF_THRESHOLD", 8u);
     static const uint32_t blocks_per_cu = env_u32("GPURT_BLOCKS_PER_CU", 3u);
     static const uint32_t sort_rays = env_u32("GPURT_SORT_RAYS", 1u);
 
@@ -693,7 +717,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     p.num_materials = (uint32_t)(materials->bytes / sizeof(rt_pbr_material));
     p.num_textures = (uint32_t)(texture_ids->bytes / sizeof(rt_texture_id));
     p.leaf_threshold = leaf_threshold < 1u ? 1u : (leaf_threshold > 64u ? 64u : leaf_threshold);
-    p.queue_chunk = (((nr + 7u) / 8u) + 63u) & ~63u;
+    p.queue_chunk = ((((nr + 63u) / 64u) + 7u) / 8u) * 64u;          // blocks of 64 rays, dealt to the eight queues in turn
     p.lv.count = 0;
     if (use_bvh) {
         if (!rt_make_levels(p.num_prims, &p.lv)) return RT_ERR_TOO_FEW_PRIMITIVES;
@@ -737,12 +761,6 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     uint32_t groups = (uint32_t)cus * (blocks_per_cu ? blocks_per_cu : 1u);
     if (groups > grid.x) groups = grid.x;
     const float4* ray_in = (const float4*)rays->ptr;
-    uint2* order = nullptr;
-    if (sort_rays) {
-        hipLaunchKernelGGL(k_ray_keys, grid, block, 0, s, nr, ray_in, nodes, dev->ray_keys_a);
-        rc = rt_sort_pairs(dev, dev->ray_keys_a, dev->ray_keys_b, nr, 3u, &order);      // 24-bit keys
-        if (rc) return rc;
-    }
     // the walk runs on the private copy of the hierarchy; a call without an accel gets one made from its buffers
     const float4* pairs = nullptr;
     if (accel) {
@@ -755,6 +773,19 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         if (rc) return rc;
         pairs = (const float4*)dev->conv_pairs;
         st = (const float4*)dev->conv_tris;
+    }
+    uint2* order = nullptr;
+    if (sort_rays) {
+        // walk-length estimate from the nodes at depth 8 (or the deepest level above the leaves of a small tree)
+        const uint32_t root_level = p.lv.count - 1u;
+        const uint32_t depth = root_level > 8u ? 8u : (root_level > 1u ? root_level - 1u : 1u);
+        const uint32_t nodes_there = p.lv.n[root_level - depth];
+        uint32_t cost_shift = 0u;
+        while ((nodes_there >> cost_shift) > 63u) cost_shift++;
+        hipLaunchKernelGGL(k_ray_keys, grid, block, 0, s, nr, ray_in, nodes, pairs, 1u << (depth - 1u), (nodes_there + 1u) / 2u,
+                           cost_shift, dev->ray_keys_a);
+        rc = rt_sort_pairs(dev, dev->ray_keys_a, dev->ray_keys_b, nr, 3u, &order);      // 24-bit keys
+        if (rc) return rc;
     }
     // waiting leaves; the counting variant also keeps the entry distances of noted children, one row per depth
     const size_t lds_bytes = ((size_t)kFifo * 512u + (stats ? (size_t)p.lv.count * 256u : 0u)) * sizeof(uint32_t);
