@@ -701,7 +701,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
 
     // tuning knobs (read once): GPURT_TRACE_KERNEL=simple selects the one-thread-per-ray kernel
     static const bool simple_kernel = [] { const char* v = std::getenv("GPURT_TRACE_KERNEL"); return v && !std::strcmp(v, "simple"); }();
-    static const uint32_t leaf_threshold = env_u32("GPURT_LEAF_THRESHOLD", 8u);
+    static const uint32_t leaf_threshold = env_u32("GPURT_LEAF_THRESHOLD", 12u);
     static const uint32_t blocks_per_cu = env_u32("GPURT_BLOCKS_PER_CU", 3u);
     static const uint32_t sort_rays = env_u32("GPURT_SORT_RAYS", 1u);
 

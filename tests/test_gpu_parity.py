@@ -203,7 +203,8 @@ def _render_both(device, oracle, sc, w, h, calls, rpp=1, depth=3, use_bvh=True, 
     op.render(calls)
     out = (gp.output_image(), op.output(), gp.result_image(), op.result(),
            gp.emitted.download(np.float32, 4 * w * h * rpp).reshape(-1, 4), op.emitted(),
-           gp.rays.download(np.float32, 8 * w * h * rpp).reshape(-1, 8), op.rays().view(np.float32).reshape(-1, 8))
+           gp.rays.download(np.float32, 8 * w * h * rpp).reshape(-1, 8), op.rays().view(np.float32).reshape(-1, 8),
+           op.stats()[1])
     gp.close()
     op.close()
     return out
@@ -223,7 +224,7 @@ def _report(name, g, o):
                                                    (20000, 64, 36, 3, False)])
 def test_traced_images_match_oracle(device, oracle, n, w, h, calls, use_accel):
     sc = _scene(n)
-    g_out, o_out, g_res, o_res, g_em, o_em, g_rays, o_rays = _render_both(device, oracle, sc, w, h, calls, use_accel=use_accel)
+    g_out, o_out, g_res, o_res, g_em, o_em, g_rays, o_rays = _render_both(device, oracle, sc, w, h, calls, use_accel=use_accel)[:8]
     assert np.isfinite(o_out).all()
     m1, _ = _report("tone-mapped", g_out, o_out)
     _report("result", g_res, o_res)
@@ -231,6 +232,40 @@ def test_traced_images_match_oracle(device, oracle, n, w, h, calls, use_accel):
     _report("rays", g_rays, o_rays)
     assert m1 <= IMAGE_TOL
     assert o_out[..., :3].max() > 0.0, "the test image must not be black"
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 1023, 1025, 2049])
+@pytest.mark.parametrize("use_accel", [True, False])
+def test_small_and_odd_triangle_counts_trace_exactly(device, oracle, n, use_accel):
+    """Every shape of the balanced hierarchy near its corner cases: two leaves, only children on several levels,
+    counts just below, at and above powers of two. Rays that miss everything leave their pixel untouched."""
+    sc = _small_scene(n, seed=100 + n)
+    g = _render_both(device, oracle, sc, 48, 32, 4, depth=2, use_accel=use_accel)
+    for name, a, b in (("tone-mapped", g[0], g[1]), ("result", g[2], g[3]), ("emitted", g[4], g[5]), ("rays", g[6], g[7])):
+        assert a.view(np.uint32).tobytes() == b.view(np.uint32).tobytes(), "%s differs at %d triangles" % (name, n)
+    assert g[8]["rays_hit"] > 0, "some ray must hit"
+
+
+def test_traverse_timing_reports_every_launch(device, oracle):
+    """rt_device_set_traverse_timing brackets the traversal kernel of every trace call with events."""
+    from gpuraytracer_amd.pipeline import Pipeline
+    sc = _scene(2000)
+    w, h = 64, 36
+    cam = sc["camera"]
+    iv, ip = oracle.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], w / h, cam["near_z"], cam["far_z"])
+    gp = Pipeline(device, sc, w, h, iv, ip)
+    assert device.lib.rt_device_set_traverse_timing(device.handle, 1) == 0
+    gp.render(5)
+    total, launches = C.c_double(-1.0), C.c_uint32(0)
+    assert device.lib.rt_device_traverse_timing(device.handle, C.byref(total), C.byref(launches)) == 0
+    assert launches.value == 5 and total.value > 0.0
+    assert device.lib.rt_device_traverse_timing(device.handle, C.byref(total), C.byref(launches)) == 0
+    assert launches.value == 0 and total.value == 0.0            # read once, then forgotten
+    assert device.lib.rt_device_set_traverse_timing(device.handle, 0) == 0
+    gp.render(1)
+    assert device.lib.rt_device_traverse_timing(device.handle, C.byref(total), C.byref(launches)) == 0
+    assert launches.value == 0
+    gp.close()
 
 
 def test_traced_image_without_bvh_matches_oracle(device, oracle):
