@@ -6,10 +6,12 @@
 
 One step = one frame of the workload: rebuild the LBVH (Morton codes, radix sort, leaves, levels),
 generate camera rays, trace `depth` bounces (each followed by the final-image pass), and - with more
-than one GPU - gather the image bands to rank 0. Inputs are resident in HBM before the timed region.
-Default workload ("c3"): the 1M-triangle synthetic scene at 3840x2160, 1 ray per pixel, 4 bounces,
-LBVH rebuilt every frame. With N GPUs the image is cut into N bands of rows (strong scaling: the
-frame is fixed), the scene and hierarchy are replicated and rebuilt on every GPU.
+than one GPU - gather the finished image rows to rank 0. Inputs are resident in HBM before the timed
+region. Default workload ("c3"): the 1M-triangle synthetic scene at 3840x2160, 1 ray per pixel,
+4 bounces, LBVH rebuilt every frame. With N GPUs the image rows are dealt out in turn (rank r owns rows
+r, r + N, ...), the scene and hierarchy are replicated and rebuilt on every GPU, and the frame carries
+N rays per pixel (weak scaling: every GPU traces width x height rays per bounce, as the single GPU
+does; --scaling strong keeps 1 ray per pixel instead).
 
 Rank 0 prints ONE JSON line: Mrays/s over the whole job (a ray = one ray segment handled by one trace
 thread in one trace launch), the LBVH build time, a roofline object for the dominant kernel (the
@@ -57,6 +59,11 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: rays per pixel grow with the GPU count; strong: the frame is fixed")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo lets several ranks rehearse on one GPU")
+    ap.add_argument("--band", default="", help="R/N: single process doing the share of rank R of N (load-balance probe)")
     ap.add_argument("--cpu-sample-div", type=int, default=4, help="CPU baseline traces the image reduced by this factor per axis")
     args = ap.parse_args()
 
@@ -64,7 +71,7 @@ def main():
     import torch.distributed as dist
 
     from gpuraytracer_amd import host_py, scenes
-    from gpuraytracer_amd.distributed import band_for_rank, gather_bands
+    from gpuraytracer_amd.distributed import gather_rows, rows_for_rank
     from gpuraytracer_amd.pipeline import Pipeline
     from gpuraytracer_amd.runtime import Device
 
@@ -75,9 +82,14 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs the torch.distributed launcher (one rank per GPU)" % args.gpus)
         args.gpus = world
+    if args.backend == "gloo":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     ntri, width, height, rpp, depth, desc = WORKLOADS[args.workload]
     ntri = args.triangles or ntri
@@ -93,7 +105,12 @@ def main():
     rs = iter(scenes.mt19937_raw(1, 3 * total_frames).reshape(-1, 3))
     ts = iter(scenes.mt19937_raw(2, 3 * total_frames * depth).reshape(-1, 3))
 
-    first_row, num_rows = band_for_rank(height, world, rank)
+    share_rank, share_world = rank, world
+    if args.band and world == 1:
+        share_rank, share_world = (int(x) for x in args.band.split("/"))
+    if args.scaling == "weak":
+        rpp *= share_world
+    first_row, num_rows, row_stride = rows_for_rank(height, share_world, share_rank)
     stream = torch.cuda.Stream()
     dev = Device(local_rank)
     with torch.cuda.stream(stream):
@@ -101,7 +118,7 @@ def main():
         band = torch.zeros((num_rows, width, 4), dtype=torch.float32, device="cuda")
         pipe = Pipeline(dev, scene, width, height, iv, ip, rpp=rpp, depth=depth, use_bvh=True, use_accel=True,
                         raygen_seeds=lambda: next(rs), trace_seeds=lambda: next(ts), first_row=first_row, num_rows=num_rows,
-                        rebuild_every_cycle=True, output_ptr=band.data_ptr())
+                        row_stride=row_stride, rebuild_every_cycle=True, output_ptr=band.data_ptr())
 
         build_events, trace_events = [], []
         raw_build, raw_trace = pipe.build, pipe.trace
@@ -124,7 +141,7 @@ def main():
         def step():
             pipe.render(depth)                       # one frame: build, camera rays, `depth` bounces
             if world > 1:
-                return gather_bands(band, height, width)
+                return gather_rows(band, height, width)
             return band
 
         for _ in range(args.warmup):
@@ -144,7 +161,7 @@ def main():
         timing["on"] = False
 
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
@@ -179,11 +196,13 @@ def main():
     out = {
         "metric": "Mrays/sec", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": desc if not (args.triangles or args.width or args.height) else
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (desc + (" - weak scaling: %d rays per pixel over %d GPUs" % (rpp, share_world)
+                                        if args.scaling == "weak" and share_world > 1 else ""))
+                   if not (args.triangles or args.width or args.height) else
                    "custom: synthetic %d-triangle scene, %dx%d, %d ray/pixel, %d bounces, LBVH rebuilt every frame" % (ntri, width, height, rpp, depth),
                    "triangles": ntri, "width": width, "height": height, "rays_per_pixel": rpp, "bounces": depth,
-                   "parallelism": "image bands x%d, replicated scene + per-GPU rebuild, gather to rank 0" % world},
+                   "parallelism": "image rows dealt to %d GPU(s) in turn, replicated scene + per-GPU rebuild, gather to rank 0" % world},
         "lbvh_build_ms": round(avg_build_ms, 4),
         "roofline": {"kernel": "k_traverse", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,

@@ -66,6 +66,11 @@ class TraceRaysInfo(C.Structure):
                 ("max_rays_per_pixel", C.c_uint32), ("rng_seed", C.c_uint32 * 3)]
 
 
+class ImageRows(C.Structure):
+    """Rows first_row, first_row + row_stride, ... (num_rows of them) of the image: what one device holds."""
+    _fields_ = [("first_row", C.c_uint32), ("num_rows", C.c_uint32), ("row_stride", C.c_uint32)]
+
+
 class GenerateFinalImageInfo(C.Structure):
     _fields_ = [("screen_dimensions", C.c_int32 * 2), ("max_rays_per_pixel", C.c_uint32), ("num_samples", C.c_uint32)]
 
@@ -107,15 +112,15 @@ SIGNATURES = {
     "rt_sort_sort": (C.c_int, [_P, C.POINTER(SortInfo), _P, _P, _P]),
     "rt_bvh_build_leaves": (C.c_int, [_P, C.POINTER(BVHInfo), _P, _P, _P, _P]),
     "rt_bvh_build": (C.c_int, [_P, C.POINTER(BVHInfo), _P]),
-    "rt_camera_ray_generation": (C.c_int, [_P, C.POINTER(CameraRayGenInfo), _P, _P, _P, _U32, _U32]),
-    "rt_trace_rays": (C.c_int, [_P, C.POINTER(TraceRaysInfo), C.c_int, _P, _P, _P, _P, _P, _U32, _P, _P, _P, _P, _P, _P, _U32]),
+    "rt_camera_ray_generation": (C.c_int, [_P, C.POINTER(CameraRayGenInfo), _P, _P, _P, C.POINTER(ImageRows)]),
+    "rt_trace_rays": (C.c_int, [_P, C.POINTER(TraceRaysInfo), C.c_int, _P, _P, _P, _P, _P, _U32, _P, _P, _P, _P, _P, _P, C.POINTER(ImageRows)]),
     "rt_generate_final_image": (C.c_int, [_P, C.POINTER(GenerateFinalImageInfo), _P, _P, _P, _P]),
     "rt_bvh_node_count": (_U32, [_U32]),
     "rt_accel_create": (C.c_int, [_P, _U32, C.POINTER(_P)]),
     "rt_accel_destroy": (C.c_int, [_P]),
     "rt_accel_pack": (C.c_int, [_P, _U32, _P, _P]),
     "rt_accel_build": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
-    "rt_trace_rays_accel": (C.c_int, [_P, C.POINTER(TraceRaysInfo), _P, _P, _P, _P, _P, _P, _U32, _P, _P, _P, _P, _P, _P, _U32]),
+    "rt_trace_rays_accel": (C.c_int, [_P, C.POINTER(TraceRaysInfo), _P, _P, _P, _P, _P, _P, _U32, _P, _P, _P, _P, _P, _P, C.POINTER(ImageRows)]),
 }
 
 _lib = None

@@ -73,6 +73,13 @@ static inline int rt_launch_status() {
     return e == hipSuccess ? RT_OK : RT_ERR_HIP_BASE + (int)e;
 }
 
+// rows first_row, first_row + row_stride, ... (num_rows of them) lie inside an image of the given height
+static inline bool rt_rows_fit(uint32_t first_row, uint32_t num_rows, uint32_t row_stride, uint32_t height) {
+    if (!row_stride || first_row > height) return false;
+    if (!num_rows) return true;
+    return (uint64_t)first_row + (uint64_t)(num_rows - 1u) * row_stride < height;
+}
+
 // radix sort tiling: 256 threads x RT_SORT_ITEMS keys per workgroup
 #define RT_SORT_THREADS 256
 #define RT_SORT_ITEMS 8

@@ -21,7 +21,7 @@ struct RaygenParams {
     float aa, dof;
     uint32_t rpp;
     uint32_t seed[3];
-    uint32_t first_row, num_rows;
+    uint32_t first_row, num_rows, row_stride;      // the image rows held by the buffers
 };
 
 __device__ __forceinline__ float dot4(float a0, float a1, float a2, float a3, float b0, float b1, float b2, float b3) {
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_raygen(RaygenParams p, float4* __restri
     const uint32_t x = blockIdx.x * 64u + threadIdx.x;
     const uint32_t row = blockIdx.y * 4u + threadIdx.y;
     if (x >= (uint32_t)p.width || row >= p.num_rows) return;
-    const uint32_t y = p.first_row + row;
+    const uint32_t y = p.first_row + row * p.row_stride;
     uint32_t s0 = x * (x + 17u);
     xorshift(s0);
     uint32_t sx = s0 + p.seed[0], sy = s0 + p.seed[1];
@@ -111,11 +111,13 @@ inline float h_dot4(const float a[4], const float b[4]) { return ((a[0] * b[0] +
 extern "C" {
 
 int rt_camera_ray_generation(rt_device* dev, const rt_camera_ray_gen_info* info, rt_buffer* rays, rt_buffer* old_rays,
-                             rt_buffer* ray_pixels, uint32_t first_row, uint32_t num_rows) {
+                             rt_buffer* ray_pixels, const rt_image_rows* rows) {
     if (!dev || !info || !rays || !old_rays || !ray_pixels) return RT_ERR_INVALID_ARGUMENT;
     const int32_t W = info->screen_size[0], H = info->screen_size[1];
     if (W <= 0 || H <= 0 || W > 65535 || H > 65536) return RT_ERR_INVALID_ARGUMENT;      // pixel x,y are packed in 16 bits each
-    if (first_row > (uint32_t)H || num_rows > (uint32_t)H - first_row) return RT_ERR_INVALID_ARGUMENT;
+    const uint32_t first_row = rows ? rows->first_row : 0u, num_rows = rows ? rows->num_rows : (uint32_t)H;
+    const uint32_t row_stride = rows ? rows->row_stride : 1u;
+    if (!rt_rows_fit(first_row, num_rows, row_stride, (uint32_t)H)) return RT_ERR_INVALID_ARGUMENT;
     const size_t nr = (size_t)num_rows * W * info->max_rays_per_pixel;
     if (nr > 0xffffffffull) return RT_ERR_INVALID_ARGUMENT;
     if (rays->bytes < nr * 32u || old_rays->bytes < nr * 32u || ray_pixels->bytes < nr * 4u) return RT_ERR_BUFFER_TOO_SMALL;
@@ -142,7 +144,7 @@ int rt_camera_ray_generation(rt_device* dev, const rt_camera_ray_gen_info* info,
     p.aa = info->aa_sample_spread; p.dof = info->dof_sample_spread;
     p.rpp = info->max_rays_per_pixel;
     for (int k = 0; k < 3; k++) p.seed[k] = info->rng_seed[k];
-    p.first_row = first_row; p.num_rows = num_rows;
+    p.first_row = first_row; p.num_rows = num_rows; p.row_stride = row_stride;
     const dim3 grid(((uint32_t)W + 63u) / 64u, (num_rows + 3u) / 4u), block(64, 4);
     hipLaunchKernelGGL(k_raygen, grid, block, 0, dev->stream, p, (float4*)rays->ptr, (float4*)old_rays->ptr,
                        (uint32_t*)ray_pixels->ptr);

@@ -37,7 +37,9 @@ struct TraceParams {
     int32_t width;
     uint32_t num_indices, num_rays, rpp;
     uint32_t seed[3];
-    uint32_t first_ray;
+    uint32_t first_ray;        // index in the whole image of the first ray of the device's first row
+    uint32_t row_len;          // rays per image row (width * rays per pixel)
+    uint32_t row_stride;       // the device holds every row_stride-th image row, stored one after the other
     uint32_t atlas_elems;
     uint32_t num_prims;
     uint32_t num_materials, num_textures;
@@ -150,6 +152,19 @@ struct ShadeBuffers {
     float4* emitted;
 };
 
+// Index in the whole image of the ray held in element tid of this device's buffers, and back: the device holds
+// image rows first, first + stride, ... one after the other.
+__device__ __forceinline__ uint32_t global_ray(const TraceParams& p, uint32_t tid) {
+    if (p.row_stride == 1u) return tid + p.first_ray;
+    return tid + p.first_ray + (tid / p.row_len) * (p.row_len * (p.row_stride - 1u));
+}
+__device__ __forceinline__ uint32_t local_ray(const TraceParams& p, uint32_t gid) {
+    const uint32_t g = gid - p.first_ray;
+    if (p.row_stride == 1u) return g;
+    const uint32_t row = g / p.row_len;
+    return (row / p.row_stride) * p.row_len + (g - row * p.row_len);
+}
+
 // Everything CS_TraceRays does after the closest hit is known (shader/CS_TraceRays.hlsl:241-292): light
 // buffers, shading, the scattered ray. tid is the ray's index in this device's buffers.
 __device__ __forceinline__ void shade_ray(const TraceParams& p, const ShadeBuffers& b, uint32_t tid, float4 r0, float4 r1,
@@ -162,14 +177,14 @@ __device__ __forceinline__ void shade_ray(const TraceParams& p, const ShadeBuffe
     const uint32_t pv = b.ray_pixels[tid];
     const uint32_t px = pv >> 16, py = pv & 0xffffu;
     const uint32_t off = __float_as_uint(o1.w);
-    const uint32_t idx = ((uint32_t)p.width * py + px) * p.rpp + off - p.first_ray;
+    const uint32_t idx = local_ray(p, ((uint32_t)p.width * py + px) * p.rpp + off);
     float4 S = b.scattered[idx];
     float4 E = b.emitted[idx];
 
     if (best.t != tmax_r) {
         const uint32_t ia = b.indices[best_ci], ib = b.indices[best_ci + 1], ic = b.indices[best_ci + 2];
         const rt_vertex A = b.verts[ia], B = b.verts[ib], C = b.verts[ic];
-        const uint32_t gid = tid + p.first_ray;
+        const uint32_t gid = global_ray(p, tid);
         uint32_t s0 = gid * (gid + 17u);
         xorshift(s0);
         uint32_t sx = s0 + p.seed[0], sy = s0 + p.seed[1];
@@ -683,13 +698,19 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
                  const rt_buffer* vertices, const rt_buffer* materials, const rt_buffer* texture_ids,
                  const rt_buffer* texture_atlas, uint32_t atlas_elements, rt_buffer* rays, rt_buffer* old_rays,
                  const rt_buffer* ray_pixels, rt_buffer* scattered_light, rt_buffer* emitted_light, const rt_buffer* bvh,
-                 uint32_t first_ray) {
+                 const rt_image_rows* rows) {
     if (!dev || !info || !indices || !vertices || !materials || !texture_ids || !texture_atlas || !rays || !old_rays ||
         !ray_pixels || !scattered_light || !emitted_light)
         return RT_ERR_INVALID_ARGUMENT;
     if (use_bvh && !bvh) return RT_ERR_INVALID_ARGUMENT;
     unsigned long long* stats = dev->trace_stats;
     const uint32_t nr = info->num_rays;
+    if (info->screen_dimensions[0] <= 0 || !info->max_rays_per_pixel) return RT_ERR_INVALID_ARGUMENT;
+    const uint64_t row_len = (uint64_t)info->screen_dimensions[0] * info->max_rays_per_pixel;
+    const uint32_t row_stride = rows ? rows->row_stride : 1u;
+    const uint64_t first_ray = rows ? (uint64_t)rows->first_row * row_len : 0u;
+    if (!row_stride || row_len > 0xffffffffull || first_ray > 0xffffffffull) return RT_ERR_INVALID_ARGUMENT;
+    if (rows && (uint64_t)rows->num_rows * row_len != nr) return RT_ERR_INVALID_ARGUMENT;
     if (rays->bytes < (size_t)nr * 32u || old_rays->bytes < (size_t)nr * 32u || ray_pixels->bytes < (size_t)nr * 4u ||
         scattered_light->bytes < (size_t)nr * 16u || emitted_light->bytes < (size_t)nr * 16u)
         return RT_ERR_BUFFER_TOO_SMALL;
@@ -711,7 +732,9 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     p.num_rays = nr;
     p.rpp = info->max_rays_per_pixel;
     for (int k = 0; k < 3; k++) p.seed[k] = info->rng_seed[k];
-    p.first_ray = first_ray;
+    p.first_ray = (uint32_t)first_ray;
+    p.row_len = (uint32_t)row_len;
+    p.row_stride = row_stride;
     p.atlas_elems = atlas_elements;
     p.num_prims = info->num_indices / 3u;
     p.num_materials = (uint32_t)(materials->bytes / sizeof(rt_pbr_material));
@@ -855,19 +878,19 @@ int rt_trace_rays(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, c
                   const rt_buffer* vertices, const rt_buffer* materials, const rt_buffer* texture_ids,
                   const rt_buffer* texture_atlas, uint32_t atlas_elements, rt_buffer* rays, rt_buffer* old_rays,
                   const rt_buffer* ray_pixels, rt_buffer* scattered_light, rt_buffer* emitted_light, const rt_buffer* bvh,
-                  uint32_t first_ray) {
+                  const rt_image_rows* rows) {
     return trace_common(dev, info, use_bvh, nullptr, indices, vertices, materials, texture_ids, texture_atlas, atlas_elements,
-                        rays, old_rays, ray_pixels, scattered_light, emitted_light, bvh, first_ray);
+                        rays, old_rays, ray_pixels, scattered_light, emitted_light, bvh, rows);
 }
 
 int rt_trace_rays_accel(rt_device* dev, const rt_trace_rays_info* info, const rt_accel* accel, const rt_buffer* indices,
                         const rt_buffer* vertices, const rt_buffer* materials, const rt_buffer* texture_ids,
                         const rt_buffer* texture_atlas, uint32_t atlas_elements, rt_buffer* rays, rt_buffer* old_rays,
                         const rt_buffer* ray_pixels, rt_buffer* scattered_light, rt_buffer* emitted_light, const rt_buffer* bvh,
-                        uint32_t first_ray) {
+                        const rt_image_rows* rows) {
     if (!accel) return RT_ERR_INVALID_ARGUMENT;
     return trace_common(dev, info, 1, accel, indices, vertices, materials, texture_ids, texture_atlas, atlas_elements, rays,
-                        old_rays, ray_pixels, scattered_light, emitted_light, bvh, first_ray);
+                        old_rays, ray_pixels, scattered_light, emitted_light, bvh, rows);
 }
 
 }  // extern "C"

@@ -172,8 +172,7 @@ namespace RT::GraphicsAPI
 		m_rtInfoData.rng_seed[0] = (uint32_t)m_stdPRNG();
 		m_rtInfoData.rng_seed[1] = (uint32_t)m_stdPRNG();
 		m_rtInfoData.rng_seed[2] = (uint32_t)m_stdPRNG();
-		return rt_camera_ray_generation(m_rtDevice, &m_rtInfoData, m_rtRayBuffer, m_rtOldRayBuffer, m_rtRayPixelsBuffer, 0,
-			(uint32_t)m_rtInfoData.screen_size[1]) == RT_OK;
+		return rt_camera_ray_generation(m_rtDevice, &m_rtInfoData, m_rtRayBuffer, m_rtOldRayBuffer, m_rtRayPixelsBuffer, nullptr) == RT_OK;
 	}
 
 
@@ -391,9 +390,9 @@ namespace RT::GraphicsAPI
 		rt_buffer** rtSlots = m_rtUAVDescriptorHeap->Slots;
 		if (m_bUseBVH && rtAccel)
 			return rt_trace_rays_accel(m_rtDevice, &m_rtInfoData, rtAccel, rtIndices, rtVertices, m_rtMaterialBuffer, rtTextureIDs, rtAtlas, iAtlasElements,
-				rtSlots[0], rtSlots[1], rtSlots[2], rtSlots[3], rtSlots[4], rtBVH, 0) == RT_OK;
+				rtSlots[0], rtSlots[1], rtSlots[2], rtSlots[3], rtSlots[4], rtBVH, nullptr) == RT_OK;
 		return rt_trace_rays(m_rtDevice, &m_rtInfoData, m_bUseBVH ? 1 : 0, rtIndices, rtVertices, m_rtMaterialBuffer, rtTextureIDs, rtAtlas, iAtlasElements,
-			rtSlots[0], rtSlots[1], rtSlots[2], rtSlots[3], rtSlots[4], rtBVH, 0) == RT_OK;
+			rtSlots[0], rtSlots[1], rtSlots[2], rtSlots[3], rtSlots[4], rtBVH, nullptr) == RT_OK;
 	}
 
 

@@ -3,9 +3,9 @@
 Mirrors the call order of the reference's RaytracerPipeline::Render
 (src/RaytracerPipeline.cpp:939-991): [build] -> camera rays every MAX_RAY_DEPTH calls -> trace ->
 final image. It exists for the benchmark and the parity tests; the C++ classes under
-gpuraytracer_amd/host/ are the drop-in host surface. An image band (first_row, num_rows) restricts a
-pipeline to part of the image for multi-GPU sharding; random seeds use global pixel and ray indices,
-so bands reproduce the single-device image exactly.
+gpuraytracer_amd/host/ are the drop-in host surface. (first_row, num_rows, row_stride) restricts a
+pipeline to some rows of the image for multi-GPU sharding; random seeds use global pixel and ray
+indices, so any split of the rows reproduces the single-device image exactly.
 """
 import ctypes as C
 
@@ -18,12 +18,15 @@ from .runtime import Accel, Device
 class Pipeline:
     def __init__(self, dev, scene, width, height, inverse_view, inverse_projection, rpp=1, depth=3, aa=1.5, dof=0.0,
                  use_bvh=True, use_accel=True, raygen_seeds=None, trace_seeds=None, first_row=0, num_rows=None,
-                 rebuild_every_cycle=False, output_ptr=None):
+                 row_stride=1, rebuild_every_cycle=False, output_ptr=None):
         self.dev = dev
         self.lib = dev.lib
         self.width, self.height, self.rpp, self.depth = int(width), int(height), int(rpp), int(depth)
         self.first_row = int(first_row)
-        self.num_rows = self.height - self.first_row if num_rows is None else int(num_rows)
+        self.row_stride = int(row_stride)
+        left = self.height - self.first_row
+        self.num_rows = (left + self.row_stride - 1) // self.row_stride if num_rows is None else int(num_rows)
+        self.rows = capi.ImageRows(self.first_row, self.num_rows, self.row_stride)
         self.use_bvh, self.use_accel = bool(use_bvh), bool(use_accel and use_bvh)
         self.rebuild_every_cycle = bool(rebuild_every_cycle)
         self.raygen_seeds = raygen_seeds    # callable returning 3 uint32 per camera-ray generation
@@ -42,7 +45,6 @@ class Pipeline:
         self.atlas = dev.upload(atlas)
 
         self.local_rays = self.num_rows * self.width * self.rpp
-        self.first_ray = self.first_row * self.width * self.rpp
         nr = max(self.local_rays, 1)
         self.rays = dev.alloc(32 * nr)
         self.old_rays = dev.alloc(32 * nr)
@@ -135,7 +137,7 @@ class Pipeline:
         for k in range(3):
             self.rg.rng_seed[k] = int(s[k])
         capi.check(self.lib.rt_camera_ray_generation(self.dev.handle, C.byref(self.rg), self.rays.handle, self.old_rays.handle,
-                                                     self.ray_pixels.handle, self.first_row, self.num_rows),
+                                                     self.ray_pixels.handle, C.byref(self.rows)),
                    "rt_camera_ray_generation")
 
     def trace(self):
@@ -144,7 +146,7 @@ class Pipeline:
             self.tr.rng_seed[k] = int(s[k])
         args = (self.indices.handle, self.vertices.handle, self.materials.handle, self.texture_ids.handle, self.atlas.handle,
                 self.atlas_elements, self.rays.handle, self.old_rays.handle, self.ray_pixels.handle, self.scattered.handle,
-                self.emitted.handle, self.bvh.handle if self.bvh else None, self.first_ray)
+                self.emitted.handle, self.bvh.handle if self.bvh else None, C.byref(self.rows))
         if self.use_accel:
             capi.check(self.lib.rt_trace_rays_accel(self.dev.handle, C.byref(self.tr), self.accel.handle, *args),
                        "rt_trace_rays_accel")

@@ -64,6 +64,12 @@ typedef struct { uint32_t num_children, previous_index, current_index, padding; 
 typedef struct { int32_t screen_dimensions[2]; uint32_t num_indices, num_rays, max_rays_per_pixel; uint32_t rng_seed[3]; } rt_trace_rays_info; /* 32 B */
 typedef struct { int32_t screen_dimensions[2]; uint32_t max_rays_per_pixel; uint32_t num_samples; } rt_generate_final_image_info;             /* 16 B */
 
+/* Rows of the image whose rays a device holds (multi-GPU sharding; no counterpart in the reference, which
+ * renders the whole image on one device): rows first_row, first_row + row_stride, ..., num_rows of them,
+ * stored one after the other. {0, height, 1} is the whole image; a NULL pointer means the same. A stride
+ * equal to the number of devices deals the rows out in turn, which balances the load better than bands. */
+typedef struct { uint32_t first_row, num_rows, row_stride; } rt_image_rows;
+
 /* ---- device, stream, events: replaces DX12Device (src/GPUDevice.h:17-38) and
  *      GPUScheduler::Record/Execute/Flush (src/GPUScheduler.cpp:130-166) ---- */
 int rt_device_create(int gpu_index, rt_device** out);
@@ -129,20 +135,22 @@ int rt_bvh_build_leaves(rt_device* dev, const rt_bvh_info* info, const rt_buffer
 int rt_bvh_build(rt_device* dev, const rt_bvh_info* info, rt_buffer* bvh);
 /* shader/CS_CameraRayGeneration.hlsl (src/RaytracerPipeline.cpp:105-150). ray_pixels: uint32 per ray
  * ((x << 16) | y), the packing of the reference's uint4 array read as a flat uint array.
- * first_row / num_rows restrict generation to an image band whose buffers start at row first_row
- * (multi-GPU tiles); pass 0, screen height for the whole image. */
+ * rows restricts generation to the image rows this device holds (NULL: the whole image); pixel
+ * coordinates and random seeds stay those of the whole image. */
 int rt_camera_ray_generation(rt_device* dev, const rt_camera_ray_gen_info* info, rt_buffer* rays, rt_buffer* old_rays,
-                             rt_buffer* ray_pixels, uint32_t first_row, uint32_t num_rows);
+                             rt_buffer* ray_pixels, const rt_image_rows* rows);
 /* shader/CS_TraceRays.hlsl + PerRayShading.hlsli + Random.hlsli (src/RaytracerPipeline.cpp:687-729).
  * use_bvh mirrors RT_USE_BVH (src/Settings.h:13). The hierarchy must have the layout the build
  * launchers above emit for info->num_indices / 3 primitives. atlas: uint4[atlas_elements].
- * first_ray is the global index of element 0 of the per-ray buffers (0 for the whole image); it
- * enters the per-thread random seed so that image bands reproduce the single-device image. */
+ * rows names the image rows the per-ray buffers hold (NULL: the whole image, info->num_rays =
+ * width * height * rays per pixel; otherwise info->num_rays = rows->num_rows * width * rays per pixel).
+ * The per-thread random seed uses the ray's index in the whole image, so that any split of the rows
+ * reproduces the single-device image. */
 int rt_trace_rays(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, const rt_buffer* indices,
                   const rt_buffer* vertices, const rt_buffer* materials, const rt_buffer* texture_ids,
                   const rt_buffer* texture_atlas, uint32_t atlas_elements, rt_buffer* rays, rt_buffer* old_rays,
                   const rt_buffer* ray_pixels, rt_buffer* scattered_light, rt_buffer* emitted_light,
-                  const rt_buffer* bvh, uint32_t first_ray);
+                  const rt_buffer* bvh, const rt_image_rows* rows);
 /* shader/CS_GenerateFinalImage.hlsl (src/RaytracerPipeline.cpp:809-854). result: float4[W*H] running
  * mean; output: float4[W*H] tone-mapped (the reference's RGBA16F texture, kept in binary32);
  * output_half: optional uint16[4*W*H] binary16 copy, may be NULL. info->screen_dimensions[1] is
@@ -168,7 +176,7 @@ int rt_trace_rays_accel(rt_device* dev, const rt_trace_rays_info* info, const rt
                         const rt_buffer* vertices, const rt_buffer* materials, const rt_buffer* texture_ids,
                         const rt_buffer* texture_atlas, uint32_t atlas_elements, rt_buffer* rays, rt_buffer* old_rays,
                         const rt_buffer* ray_pixels, rt_buffer* scattered_light, rt_buffer* emitted_light,
-                        const rt_buffer* bvh, uint32_t first_ray);
+                        const rt_buffer* bvh, const rt_image_rows* rows);
 
 #ifdef __cplusplus
 }

@@ -167,7 +167,7 @@ def test_camera_rays_match_oracle(device, oracle, w, h, rpp, dof):
         info.rng_seed[k] = oinfo.rng_seed[k] = s
     n = w * h * rpp
     rays, old, pix = device.alloc(32 * n), device.alloc(32 * n), device.alloc(4 * n)
-    capi.check(device.lib.rt_camera_ray_generation(device.handle, C.byref(info), rays.handle, old.handle, pix.handle, 0, h), "raygen")
+    capi.check(device.lib.rt_camera_ray_generation(device.handle, C.byref(info), rays.handle, old.handle, pix.handle, None), "raygen")
     o_r, o_o, o_p = np.zeros(n, dtype=ray_dtype), np.zeros(n, dtype=ray_dtype), np.zeros(n, dtype=np.uint32)
     oracle.load().orc_camera_ray_generation(C.byref(oinfo), oracle.ptr(o_r), oracle.ptr(o_o), oracle.ptr(o_p))
     assert np.array_equal(pix.download(np.uint32, n), o_p)
@@ -181,9 +181,21 @@ def test_camera_rays_match_oracle(device, oracle, w, h, rpp, dof):
     r0, nrows = h // 3, h // 2
     nb = w * nrows * rpp
     rb, ob, pb = device.alloc(32 * nb), device.alloc(32 * nb), device.alloc(4 * nb)
-    capi.check(device.lib.rt_camera_ray_generation(device.handle, C.byref(info), rb.handle, ob.handle, pb.handle, r0, nrows), "band")
+    band = capi.ImageRows(r0, nrows, 1)
+    capi.check(device.lib.rt_camera_ray_generation(device.handle, C.byref(info), rb.handle, ob.handle, pb.handle, C.byref(band)), "band")
     assert rb.download(ray_dtype, nb).tobytes() == o_r[r0 * w * rpp:(r0 + nrows) * w * rpp].tobytes()
     assert np.array_equal(pb.download(np.uint32, nb), o_p[r0 * w * rpp:(r0 + nrows) * w * rpp])
+    # every third row from row 1 on, stored one after the other
+    nrows3 = (h - 1 + 2) // 3
+    every3 = capi.ImageRows(1, nrows3, 3)
+    capi.check(device.lib.rt_camera_ray_generation(device.handle, C.byref(info), rb.handle, ob.handle, pb.handle, C.byref(every3)), "rows")
+    want_r = o_r.reshape(h, w * rpp)[1::3].reshape(-1)
+    want_p = o_p.reshape(h, w * rpp)[1::3].reshape(-1)
+    assert nrows3 * w * rpp <= nb and len(want_r) == nrows3 * w * rpp
+    assert rb.download(ray_dtype, len(want_r)).tobytes() == want_r.tobytes()
+    assert np.array_equal(pb.download(np.uint32, len(want_p)), want_p)
+    bad = capi.ImageRows(1, nrows3 + 1, 3)
+    assert device.lib.rt_camera_ray_generation(device.handle, C.byref(info), rb.handle, ob.handle, pb.handle, C.byref(bad)) == capi.RT_ERR_INVALID_ARGUMENT
     for b in (rays, old, pix, rb, ob, pb):
         b.free()
 
@@ -292,10 +304,10 @@ def test_image_bands_reproduce_the_full_image(device, oracle):
     rs = oracle.mt19937(1, 0, 30).reshape(-1, 3)
     ts = oracle.mt19937(2, 0, 30).reshape(-1, 3)
 
-    def run(first, rows):
+    def run(first, rows, stride=1, rpp=1):
         ri, ti = iter(rs), iter(ts)
-        p = Pipeline(device, sc, w, h, iv, ip, raygen_seeds=lambda: next(ri), trace_seeds=lambda: next(ti), first_row=first,
-                     num_rows=rows)
+        p = Pipeline(device, sc, w, h, iv, ip, rpp=rpp, raygen_seeds=lambda: next(ri), trace_seeds=lambda: next(ti),
+                     first_row=first, num_rows=rows, row_stride=stride)
         p.render(calls)
         img = p.output_image()
         p.close()
@@ -304,6 +316,12 @@ def test_image_bands_reproduce_the_full_image(device, oracle):
     full = run(0, h)
     top, bottom = run(0, 17), run(17, h - 17)
     assert np.array_equal(np.concatenate([top, bottom], axis=0).view(np.uint32), full.view(np.uint32))
+    # rows dealt out in turn to three devices, two rays per pixel
+    full2 = run(0, h, rpp=2)
+    dealt = np.zeros_like(full2)
+    for r in range(3):
+        dealt[r::3] = run(r, None, stride=3, rpp=2)
+    assert np.array_equal(dealt.view(np.uint32), full2.view(np.uint32))
 
 
 def test_traversal_counters_match_oracle(device, oracle):
