@@ -120,6 +120,10 @@ SIGNATURES = {
     "rt_accel_destroy": (C.c_int, [_P]),
     "rt_accel_pack": (C.c_int, [_P, _U32, _P, _P]),
     "rt_accel_build": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
+    "rt_scene_bounds": (C.c_int, [_P, _U32, _P, _P, _P]),
+    "rt_accel_pack_bounds": (C.c_int, [_P, _U32, _P, _P, _P]),
+    "rt_accel_build_device_bounds": (C.c_int, [_P, _P, _P, _P]),
+    "rt_synthetic_animate": (C.c_int, [_P, _U32, _U32, _P, _P]),
     "rt_trace_rays_accel": (C.c_int, [_P, C.POINTER(TraceRaysInfo), _P, _P, _P, _P, _P, _P, _U32, _P, _P, _P, _P, _P, _P, C.POINTER(ImageRows)]),
 }
 

@@ -11,7 +11,10 @@
 //
 // Built with -ffp-contract=off: the Morton quantisation must round once per written operation.
 
+#include <new>
+
 #include "rt_internal.h"
+#include "rt_math.h"
 
 namespace {
 
@@ -73,10 +76,115 @@ __global__ __launch_bounds__(256) void k_pack(uint32_t n, const uint32_t* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void k_morton_packed(SceneBounds sb, uint32_t n, const float4* __restrict__ tris,
-                                                       uint2* __restrict__ keys) {
+// Centroid bounds of the mesh as the reference's loader computes them on the host (src/RaytracerMesh.cpp:342-364):
+// min / max over ((p1 + p2) + p3) * (1/3). min and max are exact, so the order of the reduction does not matter
+// for finite positions. Stage one: every workgroup strides over the triangles and leaves its bounds in
+// partials[block][6]; PACK also writes the packed triangle array (k_pack). Stage two reduces the partials.
+constexpr uint32_t kBoundsBlocks = 1024u;
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_bounds_partial(uint32_t n, const uint32_t* __restrict__ indices,
+                                                        const rt_vertex* __restrict__ verts, float4* __restrict__ tris,
+                                                        float* __restrict__ partials) {
+    __shared__ float s_red[4][6];
+    const float third = 1.0f / 3.0f;
+    float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+    float mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+        const uint32_t ci = t * 3u;
+        float p[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float* q = verts[indices[ci + k]].position;
+            p[k][0] = q[0]; p[k][1] = q[1]; p[k][2] = q[2];
+            if (PACK) tris[ci + k] = make_float4(q[0], q[1], q[2], 0.0f);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float c = ((p[0][a] + p[1][a]) + p[2][a]) * third;
+            mn[a] = fminf(mn[a], c);
+            mx[a] = fmaxf(mx[a], c);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], d, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, 64));
+        }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0u)
+        for (int a = 0; a < 3; a++) { s_red[wave][a] = mn[a]; s_red[wave][3 + a] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6u) {
+        const uint32_t a = threadIdx.x;
+        float v = s_red[0][a];
+        for (int w = 1; w < 4; w++) v = (a < 3u) ? fminf(v, s_red[w][a]) : fmaxf(v, s_red[w][a]);
+        partials[blockIdx.x * 6u + a] = v;
+    }
+}
+
+// bounds: (min.xyz, 0, max.xyz, 0), the head of the Morton-code constant buffer
+__global__ __launch_bounds__(256) void k_bounds_finish(uint32_t blocks, const float* __restrict__ partials,
+                                                       float* __restrict__ bounds) {
+    __shared__ float s_red[4][6];
+    float v[6] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    for (uint32_t b = threadIdx.x; b < blocks; b += 256u)
+#pragma unroll
+        for (int a = 0; a < 6; a++) v[a] = (a < 3) ? fminf(v[a], partials[b * 6u + a]) : fmaxf(v[a], partials[b * 6u + a]);
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float o = __shfl_xor(v[a], d, 64);
+            v[a] = (a < 3) ? fminf(v[a], o) : fmaxf(v[a], o);
+        }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0u)
+        for (int a = 0; a < 6; a++) s_red[wave][a] = v[a];
+    __syncthreads();
+    if (threadIdx.x < 8u) {
+        const uint32_t j = threadIdx.x;              // output slot: 0..2 min, 3 pad, 4..6 max, 7 pad
+        float r = 0.0f;
+        if ((j & 3u) != 3u) {
+            const uint32_t a = (j < 4u) ? j : j - 1u;
+            r = s_red[0][a];
+            for (int w = 1; w < 4; w++) r = (a < 3u) ? fminf(r, s_red[w][a]) : fmaxf(r, s_red[w][a]);
+        }
+        bounds[j] = r;
+    }
+}
+
+// The synthetic dynamic workload (no counterpart in the reference, whose scenes are static): triangle i of the
+// base mesh (vertices 3i .. 3i + 2) is moved as a whole by d = 0.25 * sin(2 pi * frac(frame / 32 + 0.618 * i)) along
+// each axis. Everything else of the vertex is copied.
+__global__ __launch_bounds__(256) void k_animate(uint32_t n, uint32_t frame, const rt_vertex* __restrict__ base,
+                                                 rt_vertex* __restrict__ out) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    float ph = (float)frame * 0.03125f + 0.618f * (float)t;
+    ph = ph - floorf(ph);
+    float s, c;
+    rtm::sincos_poly(6.2831853f * ph, &s, &c);
+    const float d = 0.25f * s;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        rt_vertex v = base[3u * t + k];
+        v.position[0] += d; v.position[1] += d; v.position[2] += d;
+        out[3u * t + k] = v;
+    }
+}
+
+// dbounds (optional): scene bounds in device memory, (min.xyz, pad, max.xyz, pad); overrides sb
+__global__ __launch_bounds__(256) void k_morton_packed(SceneBounds sb, const float* __restrict__ dbounds, uint32_t n,
+                                                       const float4* __restrict__ tris, uint2* __restrict__ keys) {
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n) return;
+    if (dbounds) {
+        sb.mn[0] = dbounds[0]; sb.mn[1] = dbounds[1]; sb.mn[2] = dbounds[2];
+        sb.mx[0] = dbounds[4]; sb.mx[1] = dbounds[5]; sb.mx[2] = dbounds[6];
+    }
     uint32_t ci = t * 3u;
     float4 a = tris[ci], b = tris[ci + 1], c = tris[ci + 2];
     uint32_t code = morton_code(a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, sb.mn, sb.mx);
@@ -727,8 +835,88 @@ int rt_accel_pack(rt_accel* a, uint32_t num_primitives, const rt_buffer* indices
     return rt_launch_status();
 }
 
+namespace {
+
+int bounds_workspace(rt_device* dev) {
+    if (!dev->bounds_partials) RT_HIP(hipMalloc((void**)&dev->bounds_partials, kBoundsBlocks * 6u * sizeof(float)));
+    return RT_OK;
+}
+
+// centroid bounds of n triangles into bounds[0..7]; tris != nullptr also writes the packed triangle array
+int launch_bounds(rt_device* dev, uint32_t n, const rt_buffer* indices, const rt_buffer* vertices, float4* tris, rt_buffer* bounds) {
+    if (indices->bytes < (size_t)n * 12u || bounds->bytes < 32u) return RT_ERR_BUFFER_TOO_SMALL;
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+    rc = bounds_workspace(dev);
+    if (rc) return rc;
+    uint32_t blocks = div_up(n, 256u);
+    if (blocks > kBoundsBlocks) blocks = kBoundsBlocks;
+    if (blocks) {
+        if (tris)
+            hipLaunchKernelGGL((k_bounds_partial<true>), dim3(blocks), dim3(256), 0, dev->stream, n, (const uint32_t*)indices->ptr,
+                               (const rt_vertex*)vertices->ptr, tris, dev->bounds_partials);
+        else
+            hipLaunchKernelGGL((k_bounds_partial<false>), dim3(blocks), dim3(256), 0, dev->stream, n, (const uint32_t*)indices->ptr,
+                               (const rt_vertex*)vertices->ptr, (float4*)nullptr, dev->bounds_partials);
+    }
+    hipLaunchKernelGGL(k_bounds_finish, dim3(1), dim3(256), 0, dev->stream, blocks, (const float*)dev->bounds_partials,
+                       (float*)bounds->ptr);
+    return rt_launch_status();
+}
+
+int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, const float* dbounds, rt_buffer* bvh,
+                rt_buffer* morton_codes);
+
+}  // namespace
+
+int rt_scene_bounds(rt_device* dev, uint32_t num_primitives, const rt_buffer* indices, const rt_buffer* vertices,
+                    rt_buffer* bounds) {
+    if (!dev || !indices || !vertices || !bounds) return RT_ERR_INVALID_ARGUMENT;
+    if (num_primitives > 0x55555555u) return RT_ERR_INVALID_ARGUMENT;
+    return launch_bounds(dev, num_primitives, indices, vertices, nullptr, bounds);
+}
+
+int rt_accel_pack_bounds(rt_accel* a, uint32_t num_primitives, const rt_buffer* indices, const rt_buffer* vertices,
+                         rt_buffer* bounds) {
+    if (!a || !indices || !vertices || !bounds) return RT_ERR_INVALID_ARGUMENT;
+    if (num_primitives < 3u) return RT_ERR_TOO_FEW_PRIMITIVES;
+    if (num_primitives > a->max_prims) return RT_ERR_INVALID_ARGUMENT;
+    int rc = launch_bounds(a->dev, num_primitives, indices, vertices, a->tris, bounds);
+    if (rc) return rc;
+    a->num_prims = num_primitives;
+    return RT_OK;
+}
+
+int rt_synthetic_animate(rt_device* dev, uint32_t num_primitives, uint32_t frame, const rt_buffer* base_vertices,
+                         rt_buffer* vertices) {
+    if (!dev || !base_vertices || !vertices) return RT_ERR_INVALID_ARGUMENT;
+    if (num_primitives > 0x55555555u) return RT_ERR_INVALID_ARGUMENT;
+    if (base_vertices->bytes < (size_t)num_primitives * 144u || vertices->bytes < (size_t)num_primitives * 144u)
+        return RT_ERR_BUFFER_TOO_SMALL;
+    if (!num_primitives) return RT_OK;
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_animate, dim3(div_up(num_primitives, 256u)), dim3(256), 0, dev->stream, num_primitives, frame,
+                       (const rt_vertex*)base_vertices->ptr, (rt_vertex*)vertices->ptr);
+    return rt_launch_status();
+}
+
 int rt_accel_build(rt_accel* a, const float scene_min[3], const float scene_max[3], rt_buffer* bvh, rt_buffer* morton_codes) {
     if (!a || !scene_min || !scene_max || !bvh) return RT_ERR_INVALID_ARGUMENT;
+    return accel_build(a, scene_min, scene_max, nullptr, bvh, morton_codes);
+}
+
+int rt_accel_build_device_bounds(rt_accel* a, const rt_buffer* bounds, rt_buffer* bvh, rt_buffer* morton_codes) {
+    if (!a || !bounds || !bvh) return RT_ERR_INVALID_ARGUMENT;
+    if (bounds->bytes < 32u) return RT_ERR_BUFFER_TOO_SMALL;
+    const float zero[3] = {0.0f, 0.0f, 0.0f};
+    return accel_build(a, zero, zero, (const float*)bounds->ptr, bvh, morton_codes);
+}
+
+namespace {
+
+int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, const float* dbounds, rt_buffer* bvh,
+                rt_buffer* morton_codes) {
     const uint32_t n = a->num_prims;
     rt_levels lv;
     if (!rt_make_levels(n, &lv)) return RT_ERR_TOO_FEW_PRIMITIVES;
@@ -739,8 +927,8 @@ int rt_accel_build(rt_accel* a, const float scene_min[3], const float scene_max[
     if (rc) return rc;
     hipStream_t s = dev->stream;
 
-    hipLaunchKernelGGL(k_morton_packed, dim3(div_up(n, 256u)), dim3(256), 0, s, make_bounds(scene_min, scene_max), n, a->tris,
-                       a->keys_a);
+    hipLaunchKernelGGL(k_morton_packed, dim3(div_up(n, 256u)), dim3(256), 0, s, make_bounds(scene_min, scene_max), dbounds, n,
+                       a->tris, a->keys_a);
     uint2* src = nullptr;
     rc = rt_sort_pairs(dev, a->keys_a, a->keys_b, n, 4u, &src);     // four passes: the sorted pairs are back in keys_a
     if (rc) return rc;
@@ -753,5 +941,7 @@ int rt_accel_build(rt_accel* a, const float scene_min[3], const float scene_max[
         hipLaunchKernelGGL(k_expand_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, n, src, (uint4*)morton_codes->ptr);
     return rt_launch_status();
 }
+
+}  // namespace
 
 }  // extern "C"

@@ -28,6 +28,7 @@ int rt_device_create(int gpu_index, rt_device** out) {
     d->hit_ci = nullptr;
     d->hit_capacity = 0;
     d->queue_counter = nullptr;
+    d->bounds_partials = nullptr;
     d->ray_keys_a = nullptr;
     d->ray_keys_b = nullptr;
     d->conv_pairs = nullptr;
@@ -54,6 +55,7 @@ int rt_device_destroy(rt_device* dev) {
     if (dev->hit_records) (void)hipFree(dev->hit_records);
     if (dev->hit_ci) (void)hipFree(dev->hit_ci);
     if (dev->queue_counter) (void)hipFree(dev->queue_counter);
+    if (dev->bounds_partials) (void)hipFree(dev->bounds_partials);
     if (dev->ray_keys_a) (void)hipFree(dev->ray_keys_a);
     if (dev->ray_keys_b) (void)hipFree(dev->ray_keys_b);
     if (dev->conv_pairs) (void)hipFree(dev->conv_pairs);

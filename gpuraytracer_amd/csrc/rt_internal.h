@@ -27,6 +27,7 @@ struct rt_device {
     rt_aabb* conv_pairs;
     float4* conv_tris;
     uint32_t conv_capacity;    // primitives the two buffers are sized for
+    float* bounds_partials;    // [kBoundsBlocks][6] per-workgroup centroid bounds of the scene-bounds reduction
     // optional event pairs around the traversal kernel (rt_device_set_traverse_timing)
     bool time_traverse;
     hipEvent_t* timing_events;      // [2 * timing_capacity]: start, stop, start, stop, ...

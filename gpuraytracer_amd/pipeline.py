@@ -18,7 +18,7 @@ from .runtime import Accel, Device
 class Pipeline:
     def __init__(self, dev, scene, width, height, inverse_view, inverse_projection, rpp=1, depth=3, aa=1.5, dof=0.0,
                  use_bvh=True, use_accel=True, raygen_seeds=None, trace_seeds=None, first_row=0, num_rows=None,
-                 row_stride=1, rebuild_every_cycle=False, output_ptr=None):
+                 row_stride=1, rebuild_every_cycle=False, output_ptr=None, dynamic=False):
         self.dev = dev
         self.lib = dev.lib
         self.width, self.height, self.rpp, self.depth = int(width), int(height), int(rpp), int(depth)
@@ -28,7 +28,11 @@ class Pipeline:
         self.num_rows = (left + self.row_stride - 1) // self.row_stride if num_rows is None else int(num_rows)
         self.rows = capi.ImageRows(self.first_row, self.num_rows, self.row_stride)
         self.use_bvh, self.use_accel = bool(use_bvh), bool(use_accel and use_bvh)
-        self.rebuild_every_cycle = bool(rebuild_every_cycle)
+        self.rebuild_every_cycle = bool(rebuild_every_cycle) or bool(dynamic)
+        # dynamic: before every rebuild the synthetic animation moves the triangles on the device, and the
+        # centroid bounds the Morton codes are scaled by are reduced on the device, too
+        self.dynamic = bool(dynamic)
+        self.frame = 0
         self.raygen_seeds = raygen_seeds    # callable returning 3 uint32 per camera-ray generation
         self.trace_seeds = trace_seeds      # callable returning 3 uint32 per trace dispatch
         self.num_indices = len(scene["indices"])
@@ -38,6 +42,8 @@ class Pipeline:
 
         self.indices = dev.upload(scene["indices"])
         self.vertices = dev.upload(scene["vertices"])
+        self.base_vertices = dev.upload(scene["vertices"]) if self.dynamic else None
+        self.bounds = dev.alloc(32) if self.dynamic else None
         self.materials = dev.upload(scene["materials"])
         self.texture_ids = dev.upload(scene["texture_ids"])
         atlas = np.ascontiguousarray(scene["atlas"], dtype=np.uint32).reshape(-1, 4)
@@ -93,7 +99,17 @@ class Pipeline:
 
     # ---- LBVH build ----
     def build_fused(self):
-        self.accel.build(self.scene_min, self.scene_max, self.bvh)
+        if self.dynamic:
+            self.accel.pack_bounds(self.num_prims, self.indices, self.vertices, self.bounds)
+            self.accel.build_device_bounds(self.bounds, self.bvh)
+        else:
+            self.accel.build(self.scene_min, self.scene_max, self.bvh)
+
+    def animate(self):
+        """Moves the triangles to their places of frame self.frame (synthetic dynamic workload)."""
+        capi.check(self.lib.rt_synthetic_animate(self.dev.handle, self.num_prims, self.frame, self.base_vertices.handle,
+                                                 self.vertices.handle), "rt_synthetic_animate")
+        self.frame += 1
 
     def build_per_shader(self):
         """SortPrimitives::Sort + BuildBVH::Build with one launch per reference dispatch."""
@@ -125,6 +141,13 @@ class Pipeline:
         capi.check(lib.rt_bvh_build(d, C.byref(root), self.bvh.handle), "rt_bvh_build")
 
     def build(self):
+        if self.dynamic:
+            self.animate()
+            if not self.use_accel:        # the per-shader launchers take the bounds from the host
+                capi.check(self.lib.rt_scene_bounds(self.dev.handle, self.num_prims, self.indices.handle, self.vertices.handle,
+                                                    self.bounds.handle), "rt_scene_bounds")
+                b = self.bounds.download(np.float32, 8)
+                self.scene_min, self.scene_max = b[0:3].copy(), b[4:7].copy()
         if self.use_accel:
             self.build_fused()
         else:
@@ -187,7 +210,7 @@ class Pipeline:
         self.dev.sync()
         if self.accel:
             self.accel.destroy()
-        for b in (self.indices, self.vertices, self.materials, self.texture_ids, self.atlas, self.rays, self.old_rays,
+        for b in (self.base_vertices, self.bounds, self.indices, self.vertices, self.materials, self.texture_ids, self.atlas, self.rays, self.old_rays,
                   self.ray_pixels, self.scattered, self.emitted, self.result, self.output, self.bvh, self.morton, self.temp,
                   self.freq):
             if b is not None:

@@ -112,6 +112,15 @@ class Accel:
     def pack(self, num_primitives, indices, vertices):
         capi.check(self.lib.rt_accel_pack(self.handle, int(num_primitives), indices.handle, vertices.handle), "rt_accel_pack")
 
+    def pack_bounds(self, num_primitives, indices, vertices, bounds):
+        """pack() that also leaves the mesh's centroid bounds (8 floats) in the device buffer `bounds`."""
+        capi.check(self.lib.rt_accel_pack_bounds(self.handle, int(num_primitives), indices.handle, vertices.handle,
+                                                 bounds.handle), "rt_accel_pack_bounds")
+
+    def build_device_bounds(self, bounds, bvh, morton=None):
+        capi.check(self.lib.rt_accel_build_device_bounds(self.handle, bounds.handle, bvh.handle,
+                                                         morton.handle if morton else None), "rt_accel_build_device_bounds")
+
     def build(self, scene_min, scene_max, bvh, morton=None):
         mn = (C.c_float * 3)(*[float(x) for x in scene_min])
         mx = (C.c_float * 3)(*[float(x) for x in scene_max])

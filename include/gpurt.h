@@ -167,10 +167,30 @@ int rt_accel_destroy(rt_accel* accel);
 /* Gathers Indices -> Vertices -> positions into the accel's packed triangle array
  * (3 x float4 per triangle, original order). Call after the mesh changes. */
 int rt_accel_pack(rt_accel* accel, uint32_t num_primitives, const rt_buffer* indices, const rt_buffer* vertices);
+/* Centroid bounds of a mesh: the scene AABB the reference's loader computes on the host
+ * (src/RaytracerMesh.cpp:342-364: min / max over ((p1 + p2) + p3) * (1/3) of every triangle), for meshes
+ * that change on the device. bounds receives float[8] = (min.xyz, 0, max.xyz, 0), the head of
+ * rt_morton_code_info. Positions must be finite (the host loop's SSE min / max depend on the order of
+ * the triangles once a NaN is involved; this reduction does not keep that order). Zero triangles give
+ * +-FLT_MAX as the host loop does. */
+int rt_scene_bounds(rt_device* dev, uint32_t num_primitives, const rt_buffer* indices, const rt_buffer* vertices,
+                    rt_buffer* bounds);
+/* rt_accel_pack and rt_scene_bounds in one pass over the mesh. */
+int rt_accel_pack_bounds(rt_accel* accel, uint32_t num_primitives, const rt_buffer* indices, const rt_buffer* vertices,
+                         rt_buffer* bounds);
 /* Morton codes, stable sort, leaves and all levels. bvh receives rt_bvh_node_count(N) nodes, bit-identical
  * to the per-shader launchers; morton_codes (optional, uint4[N]) receives the sorted (code, 3*tri, 0, 0). */
 int rt_accel_build(rt_accel* accel, const float scene_min[3], const float scene_max[3], rt_buffer* bvh,
                    rt_buffer* morton_codes);
+/* rt_accel_build with the scene bounds read from device memory (rt_scene_bounds' layout): a per-frame
+ * rebuild of a moving mesh without a round trip to the host. */
+int rt_accel_build_device_bounds(rt_accel* accel, const rt_buffer* bounds, rt_buffer* bvh, rt_buffer* morton_codes);
+/* Workload helper (no counterpart in the reference, whose scenes are static): the synthetic dynamic scene.
+ * Triangle i of base_vertices (vertices 3i .. 3i + 2, 48-byte rt_vertex) is written to vertices moved as a
+ * whole by d = 0.25 * sin(2 pi * frac(frame / 32 + 0.618 * i)) along each axis; the other vertex fields are
+ * copied. */
+int rt_synthetic_animate(rt_device* dev, uint32_t num_primitives, uint32_t frame, const rt_buffer* base_vertices,
+                         rt_buffer* vertices);
 /* rt_trace_rays reading the accel's Morton-ordered packed triangles instead of Indices -> Vertices. */
 int rt_trace_rays_accel(rt_device* dev, const rt_trace_rays_info* info, const rt_accel* accel, const rt_buffer* indices,
                         const rt_buffer* vertices, const rt_buffer* materials, const rt_buffer* texture_ids,

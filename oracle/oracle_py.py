@@ -98,6 +98,8 @@ def load():
         "orc_pipeline_create": (_P, [C.POINTER(Settings), C.c_uint64, _P, C.c_uint64, _P, C.c_uint64, _P, u32, _P, _P, u32,
                                      C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "orc_pipeline_render": (C.c_int, [_P]),
+        "orc_pipeline_set_vertices": (C.c_int, [_P, C.c_uint64, _P]),
+        "orc_synthetic_animate": (None, [u32, u32, _P, _P]),
         "orc_pipeline_output": (_P, [_P]), "orc_pipeline_result": (_P, [_P]), "orc_pipeline_bvh": (_P, [_P]),
         "orc_pipeline_morton": (_P, [_P]), "orc_pipeline_rays": (_P, [_P]), "orc_pipeline_emitted": (_P, [_P]),
         "orc_pipeline_scattered": (_P, [_P]),
@@ -133,6 +135,25 @@ def mt19937(seed, skip, count):
     out = np.zeros(count, dtype=np.uint32)
     load().orc_mt19937_draw(seed, skip, count, ptr(out))
     return out
+
+
+def scene_aabb(scene):
+    """Centroid scene bounds as the reference's loader computes them."""
+    mn, mx = (C.c_float * 3)(), (C.c_float * 3)()
+    load().orc_scene_aabb(len(scene["indices"]), ptr(scene["indices"]), ptr(scene["vertices"]), mn, mx)
+    return np.array(list(mn), dtype=np.float32), np.array(list(mx), dtype=np.float32)
+
+
+def synthetic_animate(scene, frame):
+    """The scene with its triangles at their places of `frame` of the synthetic dynamic workload (new dict,
+    bounds recomputed)."""
+    base = np.ascontiguousarray(scene["vertices"])
+    out = np.empty_like(base)
+    load().orc_synthetic_animate(len(scene["indices"]) // 3, int(frame), ptr(base), ptr(out))
+    moved = dict(scene)
+    moved["vertices"] = out
+    moved["scene_min"], moved["scene_max"] = scene_aabb(moved)
+    return moved
 
 
 def sort_primitives(scene, as_written=False):
@@ -182,6 +203,11 @@ class Pipeline:
             C.byref(s), len(scene["indices"]), ptr(scene["indices"]), len(scene["vertices"]), ptr(scene["vertices"]),
             len(scene["materials"]), ptr(scene["materials"]), len(scene["texture_ids"]), ptr(scene["texture_ids"]),
             ptr(atlas), atlas.shape[0], f3(scene["scene_min"]), f3(scene["scene_max"]))
+
+    def set_vertices(self, vertices):
+        v = np.ascontiguousarray(vertices)
+        if not self.lib.orc_pipeline_set_vertices(self.handle, len(v), ptr(v)):
+            raise ValueError("vertex count differs from the pipeline's mesh")
 
     def render(self, calls=1):
         for _ in range(calls):

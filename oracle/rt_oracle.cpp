@@ -748,6 +748,26 @@ void orc_scene_aabb(uint64_t index_count, const uint32_t* indices, const orc_ver
     scene_max[0] = mx.x; scene_max[1] = mx.y; scene_max[2] = mx.z;
 }
 
+// The synthetic dynamic workload (not part of the reference, whose scenes are static): the CPU twin of the
+// product's animation kernel. Triangle i (vertices 3i .. 3i + 2) moves as a whole by
+// d = 0.25 * sin(2 pi * frac(frame / 32 + 0.618 * i)) along each axis.
+void orc_synthetic_animate(uint32_t num_primitives, uint32_t frame, const orc_vertex* base, orc_vertex* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t ti = 0; ti < (int64_t)num_primitives; ti++) {
+        const uint32_t t = (uint32_t)ti;
+        float ph = (float)frame * 0.03125f + 0.618f * (float)t;
+        ph = ph - std::floor(ph);
+        float s, c;
+        sincos_poly(6.2831853f * ph, &s, &c);
+        const float d = 0.25f * s;
+        for (int k = 0; k < 3; k++) {
+            orc_vertex v = base[3u * t + k];
+            v.px += d; v.py += d; v.pz += d;
+            out[3u * t + k] = v;
+        }
+    }
+}
+
 // src/RaytracerMesh.cpp:99-155
 void orc_calculate_tangents(uint64_t index_count, const uint32_t* indices, orc_vertex* verts) {
     std::vector<f3> acc(index_count, mk(0.0f, 0.0f, 0.0f));
@@ -917,6 +937,16 @@ int orc_pipeline_render(orc_pipeline* p) {
     if (p->iteration == 0) { p->im.num_samples |= 0x80000000u; p->im.num_samples++; }
     else p->im.num_samples &= 0x7fffffffu;
     orc_generate_final_image(&p->im, p->emitted.data(), p->result.data(), p->output.data());
+    return 1;
+}
+
+// A mesh that moved (dynamic workloads; the reference never changes its mesh): new vertex data of the same
+// count, scene bounds recomputed as the loader does. The hierarchy is rebuilt at the start of the next sample
+// cycle when rebuild_every_cycle is set.
+int orc_pipeline_set_vertices(orc_pipeline* p, uint64_t vertex_count, const orc_vertex* vertices) {
+    if (vertex_count != p->vertices.size()) return 0;
+    p->vertices.assign(vertices, vertices + vertex_count);
+    orc_scene_aabb(p->indices.size(), p->indices.data(), p->vertices.data(), p->scene_min, p->scene_max);
     return 1;
 }
 

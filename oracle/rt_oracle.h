@@ -109,6 +109,9 @@ void orc_camera_matrices(const float position[3], const float focus[3], const fl
 /* centroid scene bounds as LoadMeshFromFile computes them (src/RaytracerMesh.cpp:342-364) */
 void orc_scene_aabb(uint64_t index_count, const uint32_t* indices, const orc_vertex* vertices,
                     float scene_min[3], float scene_max[3]);
+/* Synthetic dynamic workload (not in the reference): triangle i moves as a whole by
+ * 0.25 * sin(2 pi * frac(frame / 32 + 0.618 * i)) along each axis. CPU twin of the product's kernel. */
+void orc_synthetic_animate(uint32_t num_primitives, uint32_t frame, const orc_vertex* base, orc_vertex* out);
 /* CalculateTangents (src/RaytracerMesh.cpp:99-155) */
 void orc_calculate_tangents(uint64_t index_count, const uint32_t* indices, orc_vertex* vertices);
 /* CalculateNormals (src/RaytracerMesh.cpp:59-97) */
@@ -137,6 +140,8 @@ orc_pipeline* orc_pipeline_create(const orc_settings* s, uint64_t index_count, c
                                   uint32_t texture_count, const orc_texture_id* texture_ids,
                                   const orc_uint4* atlas, uint32_t atlas_elements,
                                   const float scene_min[3], const float scene_max[3]);
+/* replaces the vertex data (same count) and recomputes the scene bounds; 0 on a count mismatch */
+int orc_pipeline_set_vertices(orc_pipeline* p, uint64_t vertex_count, const orc_vertex* vertices);
 int orc_pipeline_render(orc_pipeline* p);              /* one Render() call = one bounce */
 const orc_float4* orc_pipeline_output(orc_pipeline* p); /* tone-mapped image, width*height */
 const orc_float4* orc_pipeline_result(orc_pipeline* p); /* accumulated ResultBuffer */

@@ -434,3 +434,151 @@ def test_rebuild_every_cycle_keeps_the_image(device, oracle):
         imgs.append(hp.output())
         hp.close()
     assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+
+
+def _bounds_of(device, sc):
+    from gpuraytracer_amd import capi
+    idx, vtx, out = device.upload(sc["indices"]), device.upload(sc["vertices"]), device.alloc(32)
+    out.upload(np.full(8, 7.0, dtype=np.float32))
+    capi.check(device.lib.rt_scene_bounds(device.handle, len(sc["indices"]) // 3, idx.handle, vtx.handle, out.handle), "rt_scene_bounds")
+    b = out.download(np.float32, 8)
+    for x in (idx, vtx, out):
+        x.free()
+    return b
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 255, 257, 4097, 300001])
+def test_scene_bounds_match_the_host_loop(device, oracle, n):
+    """The device reduction gives the centroid bounds of the loader's host loop, bit for bit."""
+    if n == 0:
+        sc = dict(_small_scene(3))
+        sc["indices"] = sc["indices"][:0]
+    else:
+        sc = _small_scene(n, seed=3 + n) if n < 1000 else _scene(n)
+    b = _bounds_of(device, sc)
+    mn, mx = oracle.scene_aabb(sc)
+    assert b[:3].tobytes() == mn.tobytes() and b[4:7].tobytes() == mx.tobytes()
+    assert b[3] == 0.0 and b[7] == 0.0
+    if n == 0:
+        assert b[0] == np.float32(3.402823466e+38) and b[4] == np.float32(-3.402823466e+38)
+
+
+@pytest.mark.parametrize("name", ["testobject4_2", "testscene2"])
+def test_scene_bounds_of_reference_assets(device, oracle, name):
+    sc = _golden_scene(name)[0]
+    b = _bounds_of(device, sc)
+    assert b[:3].tobytes() == np.asarray(sc["scene_min"], dtype=np.float32).tobytes()
+    assert b[4:7].tobytes() == np.asarray(sc["scene_max"], dtype=np.float32).tobytes()
+
+
+@pytest.mark.parametrize("frame", [0, 1, 7, 31, 32, 100000])
+def test_synthetic_animation_matches_oracle(device, oracle, frame):
+    from gpuraytracer_amd import capi
+    from gpuraytracer_amd.capi import vertex_dtype
+    sc = _scene(5003)
+    n = len(sc["indices"]) // 3
+    base, out = device.upload(sc["vertices"]), device.alloc(48 * 3 * n)
+    capi.check(device.lib.rt_synthetic_animate(device.handle, n, frame, base.handle, out.handle), "rt_synthetic_animate")
+    want = oracle.synthetic_animate(sc, frame)["vertices"]
+    got = out.download(vertex_dtype, 3 * n)
+    assert got.tobytes() == want.tobytes()
+    assert np.abs(got["position"] - sc["vertices"]["position"]).max() <= 0.25
+    base.free()
+    out.free()
+
+
+@pytest.mark.parametrize("use_accel", [True, False])
+def test_dynamic_scene_rebuild_matches_oracle(device, oracle, use_accel):
+    """The moving synthetic scene: every sample cycle animates the triangles on the device, reduces the scene
+    bounds there, rebuilds the hierarchy and traces; the oracle gets the same vertices from its own animation."""
+    from gpuraytracer_amd.pipeline import Pipeline
+    sc = _scene(6000)
+    w, h, depth, cycles = 80, 45, 3, 3
+    cam = sc["camera"]
+    iv, ip = oracle.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], w / h, cam["near_z"], cam["far_z"])
+    ri, ti = iter(oracle.mt19937(1, 0, 30).reshape(-1, 3)), iter(oracle.mt19937(2, 0, 60).reshape(-1, 3))
+    gp = Pipeline(device, sc, w, h, iv, ip, depth=depth, use_accel=use_accel, raygen_seeds=lambda: next(ri),
+                  trace_seeds=lambda: next(ti), dynamic=True)
+    op = oracle.Pipeline(sc, w, h, depth=depth, seed_raygen=1, seed_trace=2, rebuild_every_cycle=True)
+    for frame in range(cycles):
+        moved = oracle.synthetic_animate(sc, frame)
+        op.set_vertices(moved["vertices"])
+        gp.render(depth)
+        op.render(depth)
+        from gpuraytracer_amd.capi import aabb_dtype
+        nodes = device.lib.rt_bvh_node_count(gp.num_prims)
+        assert gp.bvh.download(aabb_dtype, nodes).tobytes() == op.bvh().tobytes(), "hierarchy differs in frame %d" % frame
+        m, _ = _report("dynamic frame %d" % frame, gp.output_image(), op.output())
+        assert m <= IMAGE_TOL
+    assert gp.result_image().view(np.uint32).tobytes() == op.result().view(np.uint32).tobytes()
+    gp.close()
+    op.close()
+
+
+def test_ten_million_triangle_build_properties(device, oracle):
+    """The 10M-triangle configuration, checked through properties that do not need the oracle at that size: the
+    sorted records are a permutation ordered by (code, triangle) - i.e. the stable sort - the codes are those
+    of the Morton kernel (recomputed on a sample by the oracle), every node contains its children, leaves hold
+    the sorted triangles pairwise, and the node count is the closed form."""
+    from gpuraytracer_amd import host_py
+    from gpuraytracer_amd.capi import aabb_dtype
+    from gpuraytracer_amd.runtime import Accel
+    n = 10_000_000
+    sc = host_py.synthetic_scene(n)
+    idx, vtx = device.upload(sc["indices"]), device.upload(sc["vertices"])
+    nodes = device.lib.rt_bvh_node_count(n)
+    assert nodes == 10000009
+    bvh, morton = device.alloc(32 * nodes), device.alloc(16 * n)
+    acc = Accel(device, n)
+    acc.pack(n, idx, vtx)
+    acc.build(sc["scene_min"], sc["scene_max"], bvh, morton)
+    m = _u4(morton, n)
+    code, ci = m["x"], m["y"]
+    assert np.all(code[1:] >= code[:-1]), "codes are not ascending"
+    ties = code[1:] == code[:-1]
+    assert np.all(ci[1:][ties] > ci[:-1][ties]), "equal codes must keep ascending triangle order"
+    seen = np.zeros(n, dtype=np.uint8)
+    assert np.all(ci % 3 == 0)
+    seen[ci // 3] = 1
+    assert seen.all(), "not a permutation of the triangles"
+    # codes of a sample of triangles from the oracle's Morton function
+    rng = np.random.RandomState(5)
+    sample = np.sort(rng.choice(n, 200000, replace=False)).astype(np.uint32)
+    sub = dict(sc)
+    sub["indices"] = (3 * sample[:, None] + np.arange(3, dtype=np.uint32)[None, :]).reshape(-1).astype(np.uint32)
+    omi = oracle.MortonInfo()
+    for k in range(3):
+        omi.scene_min[k] = float(sc["scene_min"][k])
+        omi.scene_max[k] = float(sc["scene_max"][k])
+    omi.num_primitives = len(sample)
+    o_m = np.zeros(len(sample), dtype=oracle.uint4_dtype)
+    o_f = np.zeros(256, dtype=oracle.uint4_dtype)
+    oracle.load().orc_generate_morton_codes(C.byref(omi), oracle.ptr(sub["indices"]), oracle.ptr(sc["vertices"]), oracle.ptr(o_m),
+                                            oracle.ptr(o_f))
+    code_of_tri = np.empty(n, dtype=np.uint32)
+    code_of_tri[ci // 3] = code
+    assert np.array_equal(code_of_tri[sample], o_m["x"])
+    # hierarchy: leaves = bounds of the sorted triangle pairs, inner nodes = union of their children
+    g = bvh.download(aabb_dtype, nodes)
+    pos = sc["vertices"]["position"]
+    leaves = (n + 1) // 2
+    tri_lo = pos[sc["indices"].reshape(-1, 3)].min(axis=1)       # [n, 3]
+    tri_hi = pos[sc["indices"].reshape(-1, 3)].max(axis=1)
+    order = ci // 3
+    lo = np.minimum(tri_lo[order[0::2]], tri_lo[order[1::2]])
+    hi = np.maximum(tri_hi[order[0::2]], tri_hi[order[1::2]])
+    assert np.array_equal(g["min"][1:1 + leaves], lo) and np.array_equal(g["max"][1:1 + leaves], hi)
+    assert np.array_equal(g["link"][1:1 + leaves, 0], ci[0::2] | 0x80000000)
+    prev, count, cur = 1, leaves, 1 + leaves
+    while count > 1:
+        parents = (count + 1) // 2
+        base = 0 if parents == 1 else cur
+        c0 = prev + 2 * np.arange(parents)
+        c1 = np.minimum(c0 + 1, prev + count - 1)
+        assert np.array_equal(g["min"][base:base + parents], np.minimum(g["min"][c0], g["min"][c1]))
+        assert np.array_equal(g["max"][base:base + parents], np.maximum(g["max"][c0], g["max"][c1]))
+        assert np.array_equal(g["link"][base:base + parents, 0], c0.astype(np.uint32))
+        prev, count, cur = cur, parents, cur + parents
+    acc.destroy()
+    for b in (idx, vtx, bvh, morton):
+        b.free()
