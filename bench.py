@@ -37,6 +37,8 @@ WORKLOADS = {
     # name: (triangles, width, height, rays/pixel, bounces, description)
     "c3": (1000000, 3840, 2160, 1, 4, "C3: synthetic 1M-triangle scene, 3840x2160, 1 ray/pixel, 4 bounces, LBVH rebuilt every frame"),
     "c4": (10000000, 3840, 2160, 1, 4, "C4: synthetic 10M-triangle scene, 3840x2160, 1 ray/pixel, 4 bounces, LBVH rebuilt every frame"),
+    "c5": (50000000, 7680, 4320, 1, 4, "C5: synthetic 50M-triangle dynamic scene (triangles move every frame, scene bounds reduced on "
+           "the device), 7680x4320, 1 ray/pixel, 4 bounces, LBVH rebuilt every frame"),
     "small": (100000, 1280, 720, 1, 3, "small: synthetic 100k-triangle scene, 1280x720, 1 ray/pixel, 3 bounces, LBVH rebuilt every frame"),
 }
 
@@ -59,6 +61,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dynamic", action="store_true", help="move the triangles on the device before every rebuild (always on for c5)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: rays per pixel grow with the GPU count; strong: the frame is fixed")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -118,7 +121,7 @@ def main():
         band = torch.zeros((num_rows, width, 4), dtype=torch.float32, device="cuda")
         pipe = Pipeline(dev, scene, width, height, iv, ip, rpp=rpp, depth=depth, use_bvh=True, use_accel=True,
                         raygen_seeds=lambda: next(rs), trace_seeds=lambda: next(ts), first_row=first_row, num_rows=num_rows,
-                        row_stride=row_stride, rebuild_every_cycle=True, output_ptr=band.data_ptr())
+                        row_stride=row_stride, dynamic=args.dynamic or args.workload == "c5", rebuild_every_cycle=True, output_ptr=band.data_ptr())
 
         build_events, trace_events = [], []
         raw_build, raw_trace = pipe.build, pipe.trace

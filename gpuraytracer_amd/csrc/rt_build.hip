@@ -394,12 +394,12 @@ __device__ __forceinline__ void store_node(rt_aabb* nodes, uint32_t idx, const B
     p[1] = make_float4(b.mx[1], b.mx[2], __uint_as_float(l0), __uint_as_float(l1));
 }
 
-// The two triangles of a leaf, interleaved for the packed two-triangle test (80 bytes):
+// The two triangles of a leaf, interleaved for the packed two-triangle test (80 bytes, one leaf per 128-byte line):
 //   (a0.x a1.x a0.y a1.y) (a0.z a1.z b0.x b1.x) (b0.y b1.y b0.z b1.z) (c0.x c1.x c0.y c1.y) (c0.z c1.z ci0 ci1)
 // p[0..2] = corners of triangle 0, p[3..5] of triangle 1 (a copy of triangle 0, ci1 = 0xffffffff, if there is none)
 __device__ __forceinline__ void store_leaf_triangles(float4* sorted_tris, uint32_t leaf, const float (*p)[3], uint32_t ci0,
                                                      uint32_t ci1) {
-    float4* o = sorted_tris + 5 * (size_t)leaf;
+    float4* o = sorted_tris + RT_LEAF_STRIDE * (size_t)leaf;
     o[0] = make_float4(p[0][0], p[3][0], p[0][1], p[3][1]);
     o[1] = make_float4(p[0][2], p[3][2], p[1][0], p[4][0]);
     o[2] = make_float4(p[1][1], p[4][1], p[1][2], p[4][2]);
@@ -602,6 +602,30 @@ __global__ __launch_bounds__(256) void k_pairs_from_nodes(rt_levels lv, uint32_t
     store_pair(pairs, lv.aoff[k] + i, ba, bb, __float_as_uint(ahi.z), __float_as_uint(ahi.w), b0, b1);
 }
 
+// The four-grandchildren records (rt_quad_records) from the pair records: the record of slot h is the pair records
+// of its children 2h and 2h + 1 one after the other. One thread per slot below 2^(root level - 1); slots an odd number
+// of levels above the leaves, and slots of nodes that do not exist, have no record.
+__global__ __launch_bounds__(256) void k_quads_from_pairs(rt_levels lv, uint32_t slots, const float4* __restrict__ pairs,
+                                                          float4* __restrict__ quads) {
+    const uint32_t h = blockIdx.x * 256u + threadIdx.x;
+    if (h == 0u || h >= slots) return;
+    const uint32_t root_level = lv.count - 1u;
+    const uint32_t depth = 31u - (uint32_t)__builtin_clz(h);
+    const uint32_t k = root_level - depth;                    // the node's level above the leaves
+    if ((k & 1u) || k < 2u) return;
+    const uint32_t i = h - (1u << depth);
+    if (i >= lv.n[k]) return;
+    const float4* a = pairs + 4 * (size_t)(2u * h);
+    float4* o = quads + 8 * (size_t)h;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
+    if (2u * i + 1u < lv.n[k - 1u]) {
+        o[3] = a[4]; o[4] = a[5]; o[5] = a[6];
+    } else {
+        const float nan = __uint_as_float(0x7fc00000u);
+        o[3] = o[4] = o[5] = make_float4(nan, nan, nan, nan);
+    }
+}
+
 // ... and the Morton-ordered packed triangles from the leaves' links
 __global__ __launch_bounds__(256) void k_tris_from_leaves(uint32_t leaves, const rt_aabb* __restrict__ nodes,
                                                           const uint32_t* __restrict__ indices, const rt_vertex* __restrict__ verts,
@@ -631,7 +655,7 @@ inline SceneBounds make_bounds(const float* mn, const float* mx) {
 }  // namespace
 
 int rt_private_copy_from_reference(rt_device* dev, uint32_t num_prims, const rt_aabb* nodes, const uint32_t* indices,
-                                   const rt_vertex* verts, rt_aabb* pairs, float4* sorted_tris) {
+                                   const rt_vertex* verts, rt_aabb* pairs, float4* sorted_tris, float4* quads) {
     rt_levels lv;
     if (!rt_make_levels(num_prims, &lv)) return RT_ERR_TOO_FEW_PRIMITIVES;
     uint32_t total_pairs = 0u;
@@ -639,6 +663,11 @@ int rt_private_copy_from_reference(rt_device* dev, uint32_t num_prims, const rt_
     hipLaunchKernelGGL(k_pairs_from_nodes, dim3(div_up(total_pairs, 256u)), dim3(256), 0, dev->stream, lv, total_pairs, nodes, pairs);
     hipLaunchKernelGGL(k_tris_from_leaves, dim3(div_up(lv.n[0], 256u)), dim3(256), 0, dev->stream, lv.n[0], nodes, indices, verts,
                        sorted_tris);
+    if (quads && lv.count >= 3u) {
+        const uint32_t slots = (uint32_t)rt_quad_records(&lv);
+        hipLaunchKernelGGL(k_quads_from_pairs, dim3(div_up(slots, 256u)), dim3(256), 0, dev->stream, lv, slots, (const float4*)pairs,
+                           quads);
+    }
     return rt_launch_status();
 }
 
@@ -787,12 +816,12 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
     a->dev = dev;
     a->max_prims = max_primitives;
     a->num_prims = 0;
-    a->tris = a->sorted_tris = nullptr;
+    a->tris = a->sorted_tris = a->quads = nullptr;
     a->keys_a = a->keys_b = nullptr;
     a->pairs = nullptr;
     const size_t tri_bytes = (size_t)max_primitives * 48u, key_bytes = (size_t)max_primitives * 8u;
     hipError_t e = hipMalloc((void**)&a->tris, tri_bytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&a->sorted_tris, ((size_t)max_primitives + 1u) / 2u * 80u);   // 80 bytes per leaf
+    if (e == hipSuccess) e = hipMalloc((void**)&a->sorted_tris, ((size_t)max_primitives + 1u) / 2u * RT_LEAF_STRIDE * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc((void**)&a->keys_a, key_bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&a->keys_b, key_bytes);
     {
@@ -800,6 +829,7 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
         rt_make_levels(max_primitives, &lv);
         // a smaller scene packed later never needs more slots than the largest one
         if (e == hipSuccess) e = hipMalloc((void**)&a->pairs, (rt_aligned_node_slots(&lv) + 64u) * sizeof(rt_aabb));
+        if (e == hipSuccess) e = hipMalloc((void**)&a->quads, rt_quad_records(&lv) * 128u);
     }
     if (e != hipSuccess) {
         rt_accel_destroy(a);
@@ -815,6 +845,7 @@ int rt_accel_destroy(rt_accel* a) {
     (void)hipStreamSynchronize(a->dev->stream);
     if (a->tris) (void)hipFree(a->tris);
     if (a->sorted_tris) (void)hipFree(a->sorted_tris);
+    if (a->quads) (void)hipFree(a->quads);
     if (a->keys_a) (void)hipFree(a->keys_a);
     if (a->keys_b) (void)hipFree(a->keys_b);
     if (a->pairs) (void)hipFree(a->pairs);
@@ -937,6 +968,10 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
                        (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, a->pairs);
     for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
         hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, a->pairs);
+    if (lv.count >= 3u) {
+        const uint32_t slots = (uint32_t)rt_quad_records(&lv);
+        hipLaunchKernelGGL(k_quads_from_pairs, dim3(div_up(slots, 256u)), dim3(256), 0, s, lv, slots, (const float4*)a->pairs, a->quads);
+    }
     if (morton_codes)
         hipLaunchKernelGGL(k_expand_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, n, src, (uint4*)morton_codes->ptr);
     return rt_launch_status();

@@ -33,6 +33,7 @@ int rt_device_create(int gpu_index, rt_device** out) {
     d->ray_keys_b = nullptr;
     d->conv_pairs = nullptr;
     d->conv_tris = nullptr;
+    d->conv_quads = nullptr;
     d->conv_capacity = 0;
     d->time_traverse = false;
     d->timing_events = nullptr;
@@ -60,6 +61,7 @@ int rt_device_destroy(rt_device* dev) {
     if (dev->ray_keys_b) (void)hipFree(dev->ray_keys_b);
     if (dev->conv_pairs) (void)hipFree(dev->conv_pairs);
     if (dev->conv_tris) (void)hipFree(dev->conv_tris);
+    if (dev->conv_quads) (void)hipFree(dev->conv_quads);
     for (uint32_t i = 0; i < 2u * dev->timing_capacity; i++) (void)hipEventDestroy(dev->timing_events[i]);
     delete[] dev->timing_events;
     if (dev->owns_stream && dev->stream) (void)hipStreamDestroy(dev->stream);

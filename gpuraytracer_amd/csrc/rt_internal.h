@@ -26,6 +26,7 @@ struct rt_device {
     // private copy of the hierarchy for trace calls that come without an accel (rebuilt by every such call)
     rt_aabb* conv_pairs;
     float4* conv_tris;
+    float4* conv_quads;
     uint32_t conv_capacity;    // primitives the two buffers are sized for
     float* bounds_partials;    // [kBoundsBlocks][6] per-workgroup centroid bounds of the scene-bounds reduction
     // optional event pairs around the traversal kernel (rt_device_set_traverse_timing)
@@ -51,7 +52,8 @@ struct rt_accel {
     uint32_t max_prims;
     uint32_t num_prims;        // set by rt_accel_pack
     float4* tris;              // [3*max_prims] packed positions, original order
-    float4* sorted_tris;       // [5 * leaves] the two triangles of every leaf in Morton order, interleaved (80 bytes)
+    float4* sorted_tris;       // [RT_LEAF_STRIDE * leaves] the two triangles of every leaf in Morton order, interleaved
+    float4* quads;             // second private copy of the hierarchy, four grandchildren per 128-byte record (see rt_quad_records)
     rt_aabb* pairs;            // private copy of the hierarchy as interleaved sibling pairs (rt_levels::aoff placement)
     uint2* keys_a;             // [max_prims] (code, 3*tri)
     uint2* keys_b;             // [max_prims]
@@ -94,7 +96,7 @@ int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passe
 // rt_accel) of a hierarchy held in the reference's layout. pairs: rt_aligned_node_slots() slots;
 // sorted_tris: 5 float4 per leaf.
 int rt_private_copy_from_reference(rt_device* dev, uint32_t num_prims, const rt_aabb* nodes, const uint32_t* indices,
-                                   const rt_vertex* verts, rt_aabb* pairs, float4* sorted_tris);
+                                   const rt_vertex* verts, rt_aabb* pairs, float4* sorted_tris, float4* quads);
 
 // level schedule of the balanced hierarchy (src/RaytracerPipeline.cpp:465-467, 497-559):
 // level 0 = leaves at node 1; level k has ceil(n_{k-1} / 2) nodes appended after level k-1;
@@ -127,6 +129,16 @@ static inline bool rt_make_levels(uint32_t num_prims, rt_levels* lv) {
     for (uint32_t j = 0; j < k; j++) lv->aoff[j] = 1u << (k - 1u - j);
     return true;
 }
+// A leaf's two triangles take 80 bytes; leaves are laid out one per 128-byte line, because past the L2 a read costs
+// per line touched, not per byte (measured: random 128-byte records are fetched at the rate of 64-byte ones),
+// and an 80-byte stride makes every second leaf straddle two lines.
+#define RT_LEAF_STRIDE 8u      // in float4
+// The traversal's second copy: the node in slot h has a 128-byte record at quads[8h] with the boxes of its four
+// grandchildren (slots 4h .. 4h + 3) - the pair records of its children 2h and 2h + 1, 48 bytes each, one after the
+// other - so that one line read takes the walk two levels down. Only nodes an even number of levels above the
+// leaves have records (slots of the other depths are left unused); grandchildren that do not exist are NaNs.
+// number of 128-byte records: one per slot below 2^(root level - 1)
+static inline size_t rt_quad_records(const rt_levels* lv) { return lv->count >= 3u ? (size_t)1u << (lv->count - 2u) : 1u; }
 // 32-byte slots the private copy needs
 static inline size_t rt_aligned_node_slots(const rt_levels* lv) { return (size_t)2u << (lv->count - 1u); }
 

@@ -44,7 +44,8 @@ struct TraceParams {
     uint32_t num_prims;
     uint32_t num_materials, num_textures;
     uint32_t leaf_threshold;
-    uint32_t queue_chunk;      // slots per queue of the persistent traversal kernel (a multiple of 64)
+    uint32_t queue_chunk;      // slots per queue of the persistent traversal kernel (a multiple of the dealt block)
+    uint32_t deal_shift;       // blocks of 2^deal_shift consecutive positions of the ray order are dealt to the queues in turn
     rt_levels lv;
 };
 
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
                         // queue position -> position in the ray order (blocks of 64 positions are dealt to the eight
                         // queues in turn, so that every queue starts with long walks) -> ray
                         const uint32_t slot = mine - q_begin;
-                        const uint32_t pos = (((slot >> 6) * 8u + q) << 6) | (slot & 63u);
+                        const uint32_t pos = (((slot >> p.deal_shift) * 8u + q) << p.deal_shift) | (slot & ((1u << p.deal_shift) - 1u));
                         if (pos < p.num_rays) {                // the last block may be short: such a lane asks again
                         const uint32_t rid = order ? order[pos].y : pos;
                         const float4 r0 = rays[2 * (size_t)rid], r1 = rays[2 * (size_t)rid + 1];
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
                     wait_head = (wait_head + 1u) & (kFifo - 1u);
                     wait_n--;
                     if (__uint_as_float(e.y) < best.t) {
-                        const float4* t = sorted_tris + 5 * (size_t)e.x;
+                        const float4* t = sorted_tris + RT_LEAF_STRIDE * (size_t)e.x;
                         const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
                         const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
                         const bool two = ci1 != 0xffffffffu;
@@ -598,6 +599,367 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
     if (STATS) add_stats(stats, n_nodes, n_tris, n_hits, n_rays);
 }
 
+// ---- the same walk with a lean inner loop (the variant that runs when nothing is being counted) ----
+//
+// v_min_f32 / v_max_f32 and their three-operand forms, issued as written: the compiler otherwise guards every
+// fminf/fmaxf whose operand it cannot prove canonical with an extra instruction. Semantics are the ones the
+// rest of the library states for min/max: the operand that is not NaN wins, -0 < +0.
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+    float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+
+// Same walk, same tests, same results as k_traverse<false>; what differs is the bookkeeping:
+//  * walking lanes stay in a tight inner loop (one step per turn) that is left only when a triangle round is
+//    due, a lane has finished its ray, or nobody can walk;
+//  * a lane's state is one word w: the number of leaves it has waiting (0..kFifo), + kOver once its walk is
+//    over, or kIdle (no ray) or kDry (no ray and the queues are empty), so that every decision the wave takes
+//    together is one comparison per lane: walking w <= kFifo - 2, waiting (w & 15) != 0, finished w == kOver;
+//  * the noted second children are a trail of bits that is shifted by one per level on the way down (bit 0 =
+//    the sibling of the entered node is noted), so going back to the nearest noted child is a count of
+//    trailing zeros and two shifts;
+//  * a box is entered if !(tfar < max(tnear, lim)) && tnear != 1e30 && tnear < closest, with
+//    lim = tmin if tmin > 0, else the smallest positive float: "tfar <= 0 || tfar < tmin" of the reference's
+//    slab test (shader/CS_TraceRays.hlsl:81-97) is "tfar < lim" for every float, and its "tnear > tmax" never
+//    holds where tnear < closest <= tmax does. A missing child (a box of NaNs) fails "tnear < closest".
+// Byte offsets into the pair and leaf arrays are 32-bit: the launcher uses this kernel only below 4 GiB each.
+constexpr uint32_t kOver = 16u, kIdle = 32u, kDry = 64u;
+static_assert(kFifo <= 15u, "the waiting count shares w with the state flags");
+
+__global__ __launch_bounds__(256) void k_traverse_lean(TraceParams p, const float4* __restrict__ rays, const float4* __restrict__ nodes,
+                                                       const float4* __restrict__ pairs, const float4* __restrict__ sorted_tris,
+                                                       float4* __restrict__ hit_records, uint32_t* __restrict__ hit_ci,
+                                                       uint32_t* __restrict__ queue, const uint2* __restrict__ order) {
+    extern __shared__ uint32_t s_dyn[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t root_level = p.lv.count - 1u;
+    const uint32_t first_leaf = 1u << root_level;              // slot of leaf 0
+    const uint32_t first_leaf_parent = first_leaf >> 1;        // nodes from this slot on have leaves as children
+    uint2* s_fifo = reinterpret_cast<uint2*>(s_dyn) + tid;     // [kFifo][256] waiting leaves, this lane's column
+    const float4 root_lo = nodes[0], root_hi = nodes[1];
+    const char* pair_bytes = reinterpret_cast<const char*>(pairs);
+    const char* leaf_bytes = reinterpret_cast<const char*>(sorted_tris);
+
+    uint32_t ray = 0u;                // index of the ray this lane is walking (while w < kIdle)
+    uint32_t w = kIdle;
+    f3 org = mk(0.0f, 0.0f, 0.0f), dir = org, inv_d = org;
+    float tmin_r = 0.0f, tmax_r = 0.0f, lim = 0.0f;
+    Hit best;
+    best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
+    uint32_t best_ci = 0u;
+    uint32_t h = 1u;                  // slot of the entered node
+    uint32_t trail = 0u;              // bit j: the sibling of the walk's ancestor j levels up is noted
+    uint32_t wait_head = 0u;
+    uint32_t q = blockIdx.x & 7u, queues_tried = 0u;       // wave-uniform
+
+    for (;;) {
+        // 1. refill: every lane without a ray takes the next index; one atomic per wave (see k_traverse)
+        const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(w == kIdle);
+        if (need_mask) {
+            if (queues_tried >= 8u) {
+                if (w == kIdle) w = kDry;
+            } else {
+                const uint32_t q_begin = q * p.queue_chunk;
+                const uint32_t q_end = q_begin + p.queue_chunk;
+                const uint32_t leader = (uint32_t)__builtin_ctzll(need_mask);
+                uint32_t base = 0u;
+                if (lane == leader) base = atomicAdd(queue + 8u * q, (uint32_t)__popcll(need_mask));
+                base = q_begin + (uint32_t)__shfl((int)base, (int)leader, 64);
+                if (base >= q_end) {                               // wave-uniform: this queue is empty
+                    q = (q + 1u) & 7u;
+                    queues_tried++;
+                } else if (w == kIdle) {
+                    const uint32_t mine = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+                    if (mine < q_end) {
+                        const uint32_t slot = mine - q_begin;
+                        const uint32_t pos = (((slot >> p.deal_shift) * 8u + q) << p.deal_shift) | (slot & ((1u << p.deal_shift) - 1u));
+                        if (pos < p.num_rays) {
+                            const uint32_t rid = order ? order[pos].y : pos;
+                            const float4 r0 = rays[2 * (size_t)rid], r1 = rays[2 * (size_t)rid + 1];
+                            org = mk(r0.x, r0.y, r0.z); dir = mk(r0.w, r1.x, r1.y);
+                            tmin_r = r1.z; tmax_r = r1.w;
+                            lim = (tmin_r > 0.0f) ? tmin_r : __uint_as_float(1u);
+                            inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                            best.t = tmax_r; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
+                            best_ci = 0u;
+                            // the trunk is entered on any box hit
+                            if (slab(org, inv_d, tmin_r, tmax_r, root_lo, root_hi) != 1e30f) {
+                                ray = rid; h = 1u; trail = 0u; w = 0u;
+                            } else {
+                                hit_records[rid] = make_float4(best.t, 0.0f, 0.0f, 0.0f);
+                                hit_ci[rid] = 0u;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (!__builtin_amdgcn_ballot_w64(w < kIdle)) {
+            if (!__builtin_amdgcn_ballot_w64(w != kDry)) break;       // queues empty and nothing in flight: the wave is done
+            continue;
+        }
+
+        // 2. walk until a triangle round is due, a lane has finished its ray, or nobody can walk
+        unsigned long long waiting_mask, walking_mask;
+        for (;;) {
+            if (w <= kFifo - 2u) {
+                const float4* rec = reinterpret_cast<const float4*>(pair_bytes + (h << 6));
+                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+                const v2f ox = {org.x, org.x}, oy = {org.y, org.y}, oz = {org.z, org.z};
+                const v2f ix = {inv_d.x, inv_d.x}, iy = {inv_d.y, inv_d.y}, iz = {inv_d.z, inv_d.z};
+                const v2f ax = (v2f{q0.x, q0.y} - ox) * ix, ay = (v2f{q0.z, q0.w} - oy) * iy, az = (v2f{q1.x, q1.y} - oz) * iz;
+                const v2f bx = (v2f{q1.z, q1.w} - ox) * ix, by = (v2f{q2.x, q2.y} - oy) * iy, bz = (v2f{q2.z, q2.w} - oz) * iz;
+                const float tn0 = vmax3(vmin(ax.x, bx.x), vmin(ay.x, by.x), vmin(az.x, bz.x));
+                const float tn1 = vmax3(vmin(ax.y, bx.y), vmin(ay.y, by.y), vmin(az.y, bz.y));
+                const float tx0 = vmin3(vmax(ax.x, bx.x), vmax(ay.x, by.x), vmax(az.x, bz.x));
+                const float tx1 = vmin3(vmax(ax.y, bx.y), vmax(ay.y, by.y), vmax(az.y, bz.y));
+                const bool hit0 = !(tx0 < vmax(tn0, lim)) && (tn0 != 1e30f) && (tn0 < best.t);
+                const bool hit1 = !(tx1 < vmax(tn1, lim)) && (tn1 != 1e30f) && (tn1 < best.t);
+                if (h < first_leaf_parent && (hit0 || hit1)) {
+                    trail = (trail << 1) | ((hit0 && hit1) ? 1u : 0u);
+                    h = (h << 1) | (hit0 ? 0u : 1u);
+                } else {
+                    if (h >= first_leaf_parent) {
+                        const uint32_t leaf0 = 2u * h - first_leaf;
+                        if (hit0) {
+                            s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0, __float_as_uint(tn0));
+                            w++;
+                        }
+                        if (hit1) {
+                            s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0 + 1u, __float_as_uint(tn1));
+                            w++;
+                        }
+                    }
+                    // back to the nearest noted second child, or the walk is over
+                    if (trail == 0u) {
+                        w |= kOver;
+                    } else {
+                        const uint32_t c = (uint32_t)__builtin_ctz(trail);
+                        h = (h >> c) | 1u;
+                        trail = (trail >> c) ^ 1u;
+                    }
+                }
+            }
+            waiting_mask = __builtin_amdgcn_ballot_w64((w & 15u) != 0u);
+            walking_mask = __builtin_amdgcn_ballot_w64(w <= kFifo - 2u);
+            if (!walking_mask || (uint32_t)__popcll(waiting_mask) >= p.leaf_threshold) break;
+            if (__builtin_amdgcn_ballot_w64(w == kOver)) break;
+        }
+
+        // 3. triangle round once enough lanes have a leaf waiting (or nobody can walk any more)
+        if (waiting_mask && ((uint32_t)__popcll(waiting_mask) >= p.leaf_threshold || !walking_mask)) {
+            if ((w & 15u) != 0u) {
+                const uint2 e = s_fifo[wait_head * 256u];
+                wait_head = (wait_head + 1u) & (kFifo - 1u);
+                w--;
+                if (__uint_as_float(e.y) < best.t) {
+                    const float4* t = reinterpret_cast<const float4*>(leaf_bytes + e.x * 128u);
+                    const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
+                    const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
+                    Hit h0, h1;
+                    intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
+                    check_hit(h0, tmin_r, tmax_r, ci0, best, best_ci);
+                    if (ci1 != 0xffffffffu) check_hit(h1, tmin_r, tmax_r, ci1, best, best_ci);
+                }
+            }
+        }
+
+        // 4. a finished ray leaves its closest hit behind and frees the lane
+        if (w == kOver) {
+            hit_records[ray] = make_float4(best.t, best.u, best.v, best.w);
+            hit_ci[ray] = best_ci;
+            w = kIdle;
+        }
+    }
+}
+
+// ---- two levels per step: the walk on the four-grandchildren records ----
+//
+// Past the L2 the memory system delivers random reads at a fixed rate of 128-byte lines, whatever part of the
+// line is used, and that rate bounds the walk. One step of this kernel reads the one line that holds the boxes
+// of the entered node's four grandchildren (slots 4h .. 4h + 3) and tests all four, instead of one 64-byte record
+// for the two children and one more for every child that is hit.
+// Why the result stays the reference's: a grandchild's box lies inside its parent's, every operation of the slab
+// test is monotone, so a grandchild that passes (entry distance below the closest hit) has a parent that passes;
+// testing the grandchildren of a child that fails finds nothing. Boxes are tested earlier than in the reference's
+// walk, i.e. against a closest hit that can only be larger, which adds visits but no result: every leaf still goes
+// through the in-order list and its delayed comparison (see k_traverse).
+// Noted nodes: one nibble per step taken down; bit j of the lowest nibble = slot (h & ~3) | j waits, in order.
+// A hierarchy with an odd number of levels below the trunk starts with the trunk's two children (pair record 1).
+__global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const float4* __restrict__ rays, const float4* __restrict__ nodes,
+                                                       const float4* __restrict__ pairs, const float4* __restrict__ quads,
+                                                       const float4* __restrict__ sorted_tris, float4* __restrict__ hit_records,
+                                                       uint32_t* __restrict__ hit_ci, uint32_t* __restrict__ queue,
+                                                       const uint2* __restrict__ order) {
+    extern __shared__ uint32_t s_dyn[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t root_level = p.lv.count - 1u;               // >= 2
+    const uint32_t first_leaf = 1u << root_level;              // slot of leaf 0
+    const uint32_t first_leaf_grandparent = first_leaf >> 2;   // nodes from this slot on have leaves as grandchildren
+    const bool odd_first = (root_level & 1u) != 0u;
+    uint2* s_fifo = reinterpret_cast<uint2*>(s_dyn) + tid;     // [kFifo][256] waiting leaves, this lane's column
+    const float4 root_lo = nodes[0], root_hi = nodes[1];
+    const char* quad_bytes = reinterpret_cast<const char*>(quads);
+    const char* leaf_bytes = reinterpret_cast<const char*>(sorted_tris);
+
+    uint32_t ray = 0u;                // index of the ray this lane is walking (while w < kIdle)
+    uint32_t w = kIdle;
+    f3 org = mk(0.0f, 0.0f, 0.0f), dir = org, inv_d = org;
+    float tmin_r = 0.0f, tmax_r = 0.0f, lim = 0.0f;
+    Hit best;
+    best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
+    uint32_t best_ci = 0u;
+    uint32_t h = 1u;                  // slot of the entered node
+    unsigned long long trail = 0ull;
+    uint32_t wait_head = 0u;
+    uint32_t q = blockIdx.x & 7u, queues_tried = 0u;       // wave-uniform
+
+    for (;;) {
+        // 1. refill: every lane without a ray takes the next index; one atomic per wave (see k_traverse)
+        const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(w == kIdle);
+        if (need_mask) {
+            if (queues_tried >= 8u) {
+                if (w == kIdle) w = kDry;
+            } else {
+                const uint32_t q_begin = q * p.queue_chunk;
+                const uint32_t q_end = q_begin + p.queue_chunk;
+                const uint32_t leader = (uint32_t)__builtin_ctzll(need_mask);
+                uint32_t base = 0u;
+                if (lane == leader) base = atomicAdd(queue + 8u * q, (uint32_t)__popcll(need_mask));
+                base = q_begin + (uint32_t)__shfl((int)base, (int)leader, 64);
+                if (base >= q_end) {                               // wave-uniform: this queue is empty
+                    q = (q + 1u) & 7u;
+                    queues_tried++;
+                } else if (w == kIdle) {
+                    const uint32_t mine = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+                    if (mine < q_end) {
+                        const uint32_t slot = mine - q_begin;
+                        const uint32_t pos = (((slot >> p.deal_shift) * 8u + q) << p.deal_shift) | (slot & ((1u << p.deal_shift) - 1u));
+                        if (pos < p.num_rays) {
+                            const uint32_t rid = order ? order[pos].y : pos;
+                            const float4 r0 = rays[2 * (size_t)rid], r1 = rays[2 * (size_t)rid + 1];
+                            org = mk(r0.x, r0.y, r0.z); dir = mk(r0.w, r1.x, r1.y);
+                            tmin_r = r1.z; tmax_r = r1.w;
+                            lim = (tmin_r > 0.0f) ? tmin_r : __uint_as_float(1u);
+                            inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                            best.t = tmax_r; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
+                            best_ci = 0u;
+                            // the trunk is entered on any box hit
+                            bool walk = slab(org, inv_d, tmin_r, tmax_r, root_lo, root_hi) != 1e30f;
+                            h = 1u; trail = 0ull;
+                            if (walk && odd_first) {
+                                float bt0, bt1;
+                                slab_pair(org, inv_d, tmin_r, tmax_r, pairs[4], pairs[5], pairs[6], bt0, bt1);
+                                const bool hit0 = (bt0 != 1e30f) && (bt0 < best.t);
+                                const bool hit1 = (bt1 != 1e30f) && (bt1 < best.t);      // a missing child is NaNs: no hit
+                                walk = hit0 || hit1;
+                                h = hit0 ? 2u : 3u;
+                                trail = (hit0 && hit1) ? 8ull : 0ull;
+                            }
+                            if (walk) {
+                                ray = rid; w = 0u;
+                            } else {
+                                hit_records[rid] = make_float4(best.t, 0.0f, 0.0f, 0.0f);
+                                hit_ci[rid] = 0u;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (!__builtin_amdgcn_ballot_w64(w < kIdle)) {
+            if (!__builtin_amdgcn_ballot_w64(w != kDry)) break;       // queues empty and nothing in flight: the wave is done
+            continue;
+        }
+
+        // 2. walk until a triangle round is due, a lane has finished its ray, or nobody can walk
+        unsigned long long waiting_mask, walking_mask;
+        for (;;) {
+            if (w <= kFifo - 4u) {
+                const float4* rec = reinterpret_cast<const float4*>(quad_bytes + (h << 7));
+                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5];
+                const v2f ox = {org.x, org.x}, oy = {org.y, org.y}, oz = {org.z, org.z};
+                const v2f ix = {inv_d.x, inv_d.x}, iy = {inv_d.y, inv_d.y}, iz = {inv_d.z, inv_d.z};
+                const v2f ax = (v2f{q0.x, q0.y} - ox) * ix, ay = (v2f{q0.z, q0.w} - oy) * iy, az = (v2f{q1.x, q1.y} - oz) * iz;
+                const v2f bx = (v2f{q1.z, q1.w} - ox) * ix, by = (v2f{q2.x, q2.y} - oy) * iy, bz = (v2f{q2.z, q2.w} - oz) * iz;
+                const v2f cx = (v2f{q3.x, q3.y} - ox) * ix, cy = (v2f{q3.z, q3.w} - oy) * iy, cz = (v2f{q4.x, q4.y} - oz) * iz;
+                const v2f dx = (v2f{q4.z, q4.w} - ox) * ix, dy = (v2f{q5.x, q5.y} - oy) * iy, dz = (v2f{q5.z, q5.w} - oz) * iz;
+                const float tn0 = vmax3(vmin(ax.x, bx.x), vmin(ay.x, by.x), vmin(az.x, bz.x));
+                const float tn1 = vmax3(vmin(ax.y, bx.y), vmin(ay.y, by.y), vmin(az.y, bz.y));
+                const float tn2 = vmax3(vmin(cx.x, dx.x), vmin(cy.x, dy.x), vmin(cz.x, dz.x));
+                const float tn3 = vmax3(vmin(cx.y, dx.y), vmin(cy.y, dy.y), vmin(cz.y, dz.y));
+                const float tx0 = vmin3(vmax(ax.x, bx.x), vmax(ay.x, by.x), vmax(az.x, bz.x));
+                const float tx1 = vmin3(vmax(ax.y, bx.y), vmax(ay.y, by.y), vmax(az.y, bz.y));
+                const float tx2 = vmin3(vmax(cx.x, dx.x), vmax(cy.x, dy.x), vmax(cz.x, dz.x));
+                const float tx3 = vmin3(vmax(cx.y, dx.y), vmax(cy.y, dy.y), vmax(cz.y, dz.y));
+                const bool hit0 = !(tx0 < vmax(tn0, lim)) && (tn0 != 1e30f) && (tn0 < best.t);
+                const bool hit1 = !(tx1 < vmax(tn1, lim)) && (tn1 != 1e30f) && (tn1 < best.t);
+                const bool hit2 = !(tx2 < vmax(tn2, lim)) && (tn2 != 1e30f) && (tn2 < best.t);
+                const bool hit3 = !(tx3 < vmax(tn3, lim)) && (tn3 != 1e30f) && (tn3 < best.t);
+                const uint32_t m = (hit0 ? 1u : 0u) | (hit1 ? 2u : 0u) | (hit2 ? 4u : 0u) | (hit3 ? 8u : 0u);
+                if (h < first_leaf_grandparent && m != 0u) {
+                    trail = (trail << 4) | (unsigned long long)(m & (m - 1u));
+                    h = (h << 2) | (uint32_t)__builtin_ctz(m);
+                } else {
+                    if (h >= first_leaf_grandparent) {
+                        const uint32_t leaf0 = 4u * h - first_leaf;
+                        if (hit0) { s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0, __float_as_uint(tn0)); w++; }
+                        if (hit1) { s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0 + 1u, __float_as_uint(tn1)); w++; }
+                        if (hit2) { s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0 + 2u, __float_as_uint(tn2)); w++; }
+                        if (hit3) { s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0 + 3u, __float_as_uint(tn3)); w++; }
+                    }
+                    // back to the first noted node of the nearest level that has one, or the walk is over
+                    if (trail == 0ull) {
+                        w |= kOver;
+                    } else {
+                        const uint32_t z = (uint32_t)__builtin_ctzll(trail);
+                        const uint32_t up = z & ~3u;
+                        unsigned long long t2 = trail >> up;
+                        t2 &= t2 - 1ull;
+                        h = ((h >> (up >> 1)) & ~3u) | (z & 3u);
+                        trail = t2;
+                    }
+                }
+            }
+            waiting_mask = __builtin_amdgcn_ballot_w64((w & 15u) != 0u);
+            walking_mask = __builtin_amdgcn_ballot_w64(w <= kFifo - 4u);
+            if (!walking_mask || (uint32_t)__popcll(waiting_mask) >= p.leaf_threshold) break;
+            if (__builtin_amdgcn_ballot_w64(w == kOver)) break;
+        }
+
+        // 3. triangle round once enough lanes have a leaf waiting (or nobody can walk any more)
+        if (waiting_mask && ((uint32_t)__popcll(waiting_mask) >= p.leaf_threshold || !walking_mask)) {
+            if ((w & 15u) != 0u) {
+                const uint2 e = s_fifo[wait_head * 256u];
+                wait_head = (wait_head + 1u) & (kFifo - 1u);
+                w--;
+                if (__uint_as_float(e.y) < best.t) {
+                    const float4* t = reinterpret_cast<const float4*>(leaf_bytes + e.x * 128u);
+                    const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
+                    const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
+                    Hit h0, h1;
+                    intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
+                    check_hit(h0, tmin_r, tmax_r, ci0, best, best_ci);
+                    if (ci1 != 0xffffffffu) check_hit(h1, tmin_r, tmax_r, ci1, best, best_ci);
+                }
+            }
+        }
+
+        // 4. a finished ray leaves its closest hit behind and frees the lane
+        if (w == kOver) {
+            hit_records[ray] = make_float4(best.t, best.u, best.v, best.w);
+            hit_ci[ray] = best_ci;
+            w = kIdle;
+        }
+    }
+}
+
 // Key of every ray for the order the traversal queues hand rays out in (the reference has no such step; the
 // order rays are traced in does not enter any result).
 //  * Major part, descending: an estimate of the walk's length - how many of the nodes at one depth near the
@@ -616,7 +978,7 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {      // abcd -> a00b00
 __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float4* __restrict__ rays,
                                                   const float4* __restrict__ nodes, const float4* __restrict__ pairs,
                                                   uint32_t first_record, uint32_t num_records, uint32_t cost_shift,
-                                                  uint2* __restrict__ keys) {
+                                                  uint32_t cost_major_bits, uint2* __restrict__ keys) {
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     if (tid >= num_rays) return;
     const float4 lo = nodes[0], hi = nodes[1];
@@ -641,7 +1003,10 @@ __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float
     const uint32_t dz = (uint32_t)fminf(fmaxf(r1.y * 2.0f + 2.0f, 0.0f), 3.0f);
     const uint32_t okey = spread3(ox) | (spread3(oy) << 1) | (spread3(oz) << 2);      // 12 bits
     const uint32_t dkey = spread3(dx) | (spread3(dy) << 1) | (spread3(dz) << 2);      // 6 bits
-    keys[tid] = make_uint2(((63u - cost_class) << 18) | (okey << 6) | dkey, tid);
+    // the top cost_major_bits of the (descending) cost class lead the key, the rest of it ends the key
+    const uint32_t cinv = 63u - cost_class, minor_bits = 6u - cost_major_bits;
+    const uint32_t major = cinv >> minor_bits, minor = cinv & ((1u << minor_bits) - 1u);
+    keys[tid] = make_uint2((((major << 18) | (okey << 6) | dkey) << minor_bits) | minor, tid);
 }
 
 __global__ __launch_bounds__(256) void k_shade(TraceParams p, ShadeBuffers b, const float4* __restrict__ hit_records,
@@ -679,10 +1044,12 @@ int convert_workspace(rt_device* dev, uint32_t num_prims, const rt_levels& lv) {
     RT_HIP(hipStreamSynchronize(dev->stream));
     if (dev->conv_pairs) { (void)hipFree(dev->conv_pairs); dev->conv_pairs = nullptr; }
     if (dev->conv_tris) { (void)hipFree(dev->conv_tris); dev->conv_tris = nullptr; }
+    if (dev->conv_quads) { (void)hipFree(dev->conv_quads); dev->conv_quads = nullptr; }
     dev->conv_capacity = 0;
     // both sizes grow with the primitive count
     hipError_t e = hipMalloc((void**)&dev->conv_pairs, rt_aligned_node_slots(&lv) * sizeof(rt_aabb));
-    if (e == hipSuccess) e = hipMalloc((void**)&dev->conv_tris, (size_t)lv.n[0] * 5u * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&dev->conv_tris, (size_t)lv.n[0] * RT_LEAF_STRIDE * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&dev->conv_quads, rt_quad_records(&lv) * 128u);
     if (e != hipSuccess) return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
     dev->conv_capacity = num_prims;
     return RT_OK;
@@ -720,8 +1087,12 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     int rc = rt_set_device(dev);
     if (rc) return rc;
 
-    // tuning knobs (read once): GPURT_TRACE_KERNEL=simple selects the one-thread-per-ray kernel
+    // tuning knobs (read once): GPURT_TRACE_KERNEL=simple selects the one-thread-per-ray kernel, =wave the
+    // persistent kernel's first form (the one the counting variant is built from), =lean its lean form;
+    // the default walks two levels per step
     static const bool simple_kernel = [] { const char* v = std::getenv("GPURT_TRACE_KERNEL"); return v && !std::strcmp(v, "simple"); }();
+    static const bool quad_kernel = [] { const char* v = std::getenv("GPURT_TRACE_KERNEL"); return !v || !*v || !std::strcmp(v, "quad"); }();
+    static const bool lean_kernel = [] { const char* v = std::getenv("GPURT_TRACE_KERNEL"); return !(v && !std::strcmp(v, "wave")); }();
     static const uint32_t leaf_threshold = env_u32("GPURT_LEAF_THRESHOLD", 12u);
     static const uint32_t blocks_per_cu = env_u32("GPURT_BLOCKS_PER_CU", 3u);
     static const uint32_t sort_rays = env_u32("GPURT_SORT_RAYS", 1u);
@@ -740,7 +1111,11 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     p.num_materials = (uint32_t)(materials->bytes / sizeof(rt_pbr_material));
     p.num_textures = (uint32_t)(texture_ids->bytes / sizeof(rt_texture_id));
     p.leaf_threshold = leaf_threshold < 1u ? 1u : (leaf_threshold > 64u ? 64u : leaf_threshold);
-    p.queue_chunk = ((((nr + 63u) / 64u) + 7u) / 8u) * 64u;          // blocks of 64 rays, dealt to the eight queues in turn
+    static const uint32_t deal_shift_env = env_u32("GPURT_DEAL_SHIFT", 6u);
+    static const uint32_t cost_major_bits = env_u32("GPURT_COST_BITS", 6u) > 6u ? 6u : env_u32("GPURT_COST_BITS", 6u);
+    p.deal_shift = deal_shift_env < 6u ? 6u : (deal_shift_env > 20u ? 20u : deal_shift_env);
+    const uint32_t deal_block = 1u << p.deal_shift;
+    p.queue_chunk = ((((nr + deal_block - 1u) / deal_block) + 7u) / 8u) * deal_block;      // whole blocks, dealt to the eight queues in turn
     p.lv.count = 0;
     if (use_bvh) {
         if (!rt_make_levels(p.num_prims, &p.lv)) return RT_ERR_TOO_FEW_PRIMITIVES;
@@ -786,16 +1161,19 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     const float4* ray_in = (const float4*)rays->ptr;
     // the walk runs on the private copy of the hierarchy; a call without an accel gets one made from its buffers
     const float4* pairs = nullptr;
+    const float4* quads = nullptr;
     if (accel) {
         pairs = (const float4*)accel->pairs;
+        quads = (const float4*)accel->quads;
     } else {
         rc = convert_workspace(dev, p.num_prims, p.lv);
         if (rc) return rc;
         rc = rt_private_copy_from_reference(dev, p.num_prims, (const rt_aabb*)bvh->ptr, b.indices, b.verts, dev->conv_pairs,
-                                            dev->conv_tris);
+                                            dev->conv_tris, dev->conv_quads);
         if (rc) return rc;
         pairs = (const float4*)dev->conv_pairs;
         st = (const float4*)dev->conv_tris;
+        quads = (const float4*)dev->conv_quads;
     }
     uint2* order = nullptr;
     if (sort_rays) {
@@ -806,7 +1184,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         uint32_t cost_shift = 0u;
         while ((nodes_there >> cost_shift) > 63u) cost_shift++;
         hipLaunchKernelGGL(k_ray_keys, grid, block, 0, s, nr, ray_in, nodes, pairs, 1u << (depth - 1u), (nodes_there + 1u) / 2u,
-                           cost_shift, dev->ray_keys_a);
+                           cost_shift, cost_major_bits, dev->ray_keys_a);
         rc = rt_sort_pairs(dev, dev->ray_keys_a, dev->ray_keys_b, nr, 3u, &order);      // 24-bit keys
         if (rc) return rc;
     }
@@ -830,7 +1208,15 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         timing = dev->timing_events + 2u * dev->timing_count++;
         RT_HIP(hipEventRecord(timing[0], s));
     }
+    // the lean kernel addresses pairs and leaves with 32-bit byte offsets
+    const bool lean_fits = rt_aligned_node_slots(&p.lv) * sizeof(rt_aabb) <= 0xffffffffull && (size_t)p.lv.n[0] * 128u <= 0xffffffffull;
     if (stats) RT_LAUNCH_TRAVERSE(true);
+    else if (quad_kernel && lean_fits && p.lv.count >= 3u && quads)
+        hipLaunchKernelGGL(k_traverse_quad, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in, nodes, pairs, quads,
+                           st, dev->hit_records, dev->hit_ci, dev->queue_counter, order);
+    else if (lean_kernel && lean_fits)
+        hipLaunchKernelGGL(k_traverse_lean, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in, nodes, pairs, st,
+                           dev->hit_records, dev->hit_ci, dev->queue_counter, order);
     else RT_LAUNCH_TRAVERSE(false);
 #undef RT_LAUNCH_TRAVERSE
     if (timing) RT_HIP(hipEventRecord(timing[1], s));
