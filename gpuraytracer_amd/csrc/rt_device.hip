@@ -2,6 +2,8 @@
 // Stands in for the reference's DX12Device (src/GPUDevice.cpp:40-91), GPUScheduler
 // (src/GPUScheduler.cpp:130-166) and the buffer wrappers of src/ShaderResources.h.
 
+#include <cstdlib>
+#include <cstring>
 #include <new>
 
 #include "rt_internal.h"
@@ -35,6 +37,11 @@ int rt_device_create(int gpu_index, rt_device** out) {
     d->conv_tris = nullptr;
     d->conv_quads = nullptr;
     d->conv_capacity = 0;
+    {   // initial choice of the traversal kernel: GPURT_TRACE_KERNEL = quad (default) | wave | simple
+        const char* v = std::getenv("GPURT_TRACE_KERNEL");
+        d->trace_kernel = (v && !std::strcmp(v, "wave")) ? RT_TRACE_KERNEL_WAVE : (v && !std::strcmp(v, "simple")) ? RT_TRACE_KERNEL_SIMPLE
+                                                                                                                 : RT_TRACE_KERNEL_QUAD;
+    }
     d->time_traverse = false;
     d->timing_events = nullptr;
     d->timing_count = d->timing_capacity = 0;

@@ -30,6 +30,7 @@ struct rt_device {
     uint32_t conv_capacity;    // primitives the two buffers are sized for
     float* bounds_partials;    // [kBoundsBlocks][6] per-workgroup centroid bounds of the scene-bounds reduction
     // optional event pairs around the traversal kernel (rt_device_set_traverse_timing)
+    int trace_kernel;          // RT_TRACE_KERNEL_*: which traversal kernel rt_trace_rays launches
     bool time_traverse;
     hipEvent_t* timing_events;      // [2 * timing_capacity]: start, stop, start, stop, ...
     uint32_t timing_count, timing_capacity;

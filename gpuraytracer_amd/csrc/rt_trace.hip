@@ -599,8 +599,6 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
     if (STATS) add_stats(stats, n_nodes, n_tris, n_hits, n_rays);
 }
 
-// ---- the same walk with a lean inner loop (the variant that runs when nothing is being counted) ----
-//
 // v_min_f32 / v_max_f32 and their three-operand forms, issued as written: the compiler otherwise guards every
 // fminf/fmaxf whose operand it cannot prove canonical with an extra instruction. Semantics are the ones the
 // rest of the library states for min/max: the operand that is not NaN wins, -0 < +0.
@@ -613,170 +611,11 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
     float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
 }
 
-// Same walk, same tests, same results as k_traverse<false>; what differs is the bookkeeping:
-//  * walking lanes stay in a tight inner loop (one step per turn) that is left only when a triangle round is
-//    due, a lane has finished its ray, or nobody can walk;
-//  * a lane's state is one word w: the number of leaves it has waiting (0..kFifo), + kOver once its walk is
-//    over, or kIdle (no ray) or kDry (no ray and the queues are empty), so that every decision the wave takes
-//    together is one comparison per lane: walking w <= kFifo - 2, waiting (w & 15) != 0, finished w == kOver;
-//  * the noted second children are a trail of bits that is shifted by one per level on the way down (bit 0 =
-//    the sibling of the entered node is noted), so going back to the nearest noted child is a count of
-//    trailing zeros and two shifts;
-//  * a box is entered if !(tfar < max(tnear, lim)) && tnear != 1e30 && tnear < closest, with
-//    lim = tmin if tmin > 0, else the smallest positive float: "tfar <= 0 || tfar < tmin" of the reference's
-//    slab test (shader/CS_TraceRays.hlsl:81-97) is "tfar < lim" for every float, and its "tnear > tmax" never
-//    holds where tnear < closest <= tmax does. A missing child (a box of NaNs) fails "tnear < closest".
-// Byte offsets into the pair and leaf arrays are 32-bit: the launcher uses this kernel only below 4 GiB each.
+// A lane's state in k_traverse_quad is one word w: the number of leaves it has waiting (0..kFifo), + kOver once its
+// walk is over, or kIdle (no ray) or kDry (no ray and the queues are empty), so that every decision the wave takes
+// together is one comparison per lane: walking w <= kFifo - 4, waiting (w & 15) != 0, finished w == kOver.
 constexpr uint32_t kOver = 16u, kIdle = 32u, kDry = 64u;
 static_assert(kFifo <= 15u, "the waiting count shares w with the state flags");
-
-__global__ __launch_bounds__(256) void k_traverse_lean(TraceParams p, const float4* __restrict__ rays, const float4* __restrict__ nodes,
-                                                       const float4* __restrict__ pairs, const float4* __restrict__ sorted_tris,
-                                                       float4* __restrict__ hit_records, uint32_t* __restrict__ hit_ci,
-                                                       uint32_t* __restrict__ queue, const uint2* __restrict__ order) {
-    extern __shared__ uint32_t s_dyn[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t root_level = p.lv.count - 1u;
-    const uint32_t first_leaf = 1u << root_level;              // slot of leaf 0
-    const uint32_t first_leaf_parent = first_leaf >> 1;        // nodes from this slot on have leaves as children
-    uint2* s_fifo = reinterpret_cast<uint2*>(s_dyn) + tid;     // [kFifo][256] waiting leaves, this lane's column
-    const float4 root_lo = nodes[0], root_hi = nodes[1];
-    const char* pair_bytes = reinterpret_cast<const char*>(pairs);
-    const char* leaf_bytes = reinterpret_cast<const char*>(sorted_tris);
-
-    uint32_t ray = 0u;                // index of the ray this lane is walking (while w < kIdle)
-    uint32_t w = kIdle;
-    f3 org = mk(0.0f, 0.0f, 0.0f), dir = org, inv_d = org;
-    float tmin_r = 0.0f, tmax_r = 0.0f, lim = 0.0f;
-    Hit best;
-    best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
-    uint32_t best_ci = 0u;
-    uint32_t h = 1u;                  // slot of the entered node
-    uint32_t trail = 0u;              // bit j: the sibling of the walk's ancestor j levels up is noted
-    uint32_t wait_head = 0u;
-    uint32_t q = blockIdx.x & 7u, queues_tried = 0u;       // wave-uniform
-
-    for (;;) {
-        // 1. refill: every lane without a ray takes the next index; one atomic per wave (see k_traverse)
-        const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(w == kIdle);
-        if (need_mask) {
-            if (queues_tried >= 8u) {
-                if (w == kIdle) w = kDry;
-            } else {
-                const uint32_t q_begin = q * p.queue_chunk;
-                const uint32_t q_end = q_begin + p.queue_chunk;
-                const uint32_t leader = (uint32_t)__builtin_ctzll(need_mask);
-                uint32_t base = 0u;
-                if (lane == leader) base = atomicAdd(queue + 8u * q, (uint32_t)__popcll(need_mask));
-                base = q_begin + (uint32_t)__shfl((int)base, (int)leader, 64);
-                if (base >= q_end) {                               // wave-uniform: this queue is empty
-                    q = (q + 1u) & 7u;
-                    queues_tried++;
-                } else if (w == kIdle) {
-                    const uint32_t mine = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
-                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
-                    if (mine < q_end) {
-                        const uint32_t slot = mine - q_begin;
-                        const uint32_t pos = (((slot >> p.deal_shift) * 8u + q) << p.deal_shift) | (slot & ((1u << p.deal_shift) - 1u));
-                        if (pos < p.num_rays) {
-                            const uint32_t rid = order ? order[pos].y : pos;
-                            const float4 r0 = rays[2 * (size_t)rid], r1 = rays[2 * (size_t)rid + 1];
-                            org = mk(r0.x, r0.y, r0.z); dir = mk(r0.w, r1.x, r1.y);
-                            tmin_r = r1.z; tmax_r = r1.w;
-                            lim = (tmin_r > 0.0f) ? tmin_r : __uint_as_float(1u);
-                            inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-                            best.t = tmax_r; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
-                            best_ci = 0u;
-                            // the trunk is entered on any box hit
-                            if (slab(org, inv_d, tmin_r, tmax_r, root_lo, root_hi) != 1e30f) {
-                                ray = rid; h = 1u; trail = 0u; w = 0u;
-                            } else {
-                                hit_records[rid] = make_float4(best.t, 0.0f, 0.0f, 0.0f);
-                                hit_ci[rid] = 0u;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (!__builtin_amdgcn_ballot_w64(w < kIdle)) {
-            if (!__builtin_amdgcn_ballot_w64(w != kDry)) break;       // queues empty and nothing in flight: the wave is done
-            continue;
-        }
-
-        // 2. walk until a triangle round is due, a lane has finished its ray, or nobody can walk
-        unsigned long long waiting_mask, walking_mask;
-        for (;;) {
-            if (w <= kFifo - 2u) {
-                const float4* rec = reinterpret_cast<const float4*>(pair_bytes + (h << 6));
-                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-                const v2f ox = {org.x, org.x}, oy = {org.y, org.y}, oz = {org.z, org.z};
-                const v2f ix = {inv_d.x, inv_d.x}, iy = {inv_d.y, inv_d.y}, iz = {inv_d.z, inv_d.z};
-                const v2f ax = (v2f{q0.x, q0.y} - ox) * ix, ay = (v2f{q0.z, q0.w} - oy) * iy, az = (v2f{q1.x, q1.y} - oz) * iz;
-                const v2f bx = (v2f{q1.z, q1.w} - ox) * ix, by = (v2f{q2.x, q2.y} - oy) * iy, bz = (v2f{q2.z, q2.w} - oz) * iz;
-                const float tn0 = vmax3(vmin(ax.x, bx.x), vmin(ay.x, by.x), vmin(az.x, bz.x));
-                const float tn1 = vmax3(vmin(ax.y, bx.y), vmin(ay.y, by.y), vmin(az.y, bz.y));
-                const float tx0 = vmin3(vmax(ax.x, bx.x), vmax(ay.x, by.x), vmax(az.x, bz.x));
-                const float tx1 = vmin3(vmax(ax.y, bx.y), vmax(ay.y, by.y), vmax(az.y, bz.y));
-                const bool hit0 = !(tx0 < vmax(tn0, lim)) && (tn0 != 1e30f) && (tn0 < best.t);
-                const bool hit1 = !(tx1 < vmax(tn1, lim)) && (tn1 != 1e30f) && (tn1 < best.t);
-                if (h < first_leaf_parent && (hit0 || hit1)) {
-                    trail = (trail << 1) | ((hit0 && hit1) ? 1u : 0u);
-                    h = (h << 1) | (hit0 ? 0u : 1u);
-                } else {
-                    if (h >= first_leaf_parent) {
-                        const uint32_t leaf0 = 2u * h - first_leaf;
-                        if (hit0) {
-                            s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0, __float_as_uint(tn0));
-                            w++;
-                        }
-                        if (hit1) {
-                            s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0 + 1u, __float_as_uint(tn1));
-                            w++;
-                        }
-                    }
-                    // back to the nearest noted second child, or the walk is over
-                    if (trail == 0u) {
-                        w |= kOver;
-                    } else {
-                        const uint32_t c = (uint32_t)__builtin_ctz(trail);
-                        h = (h >> c) | 1u;
-                        trail = (trail >> c) ^ 1u;
-                    }
-                }
-            }
-            waiting_mask = __builtin_amdgcn_ballot_w64((w & 15u) != 0u);
-            walking_mask = __builtin_amdgcn_ballot_w64(w <= kFifo - 2u);
-            if (!walking_mask || (uint32_t)__popcll(waiting_mask) >= p.leaf_threshold) break;
-            if (__builtin_amdgcn_ballot_w64(w == kOver)) break;
-        }
-
-        // 3. triangle round once enough lanes have a leaf waiting (or nobody can walk any more)
-        if (waiting_mask && ((uint32_t)__popcll(waiting_mask) >= p.leaf_threshold || !walking_mask)) {
-            if ((w & 15u) != 0u) {
-                const uint2 e = s_fifo[wait_head * 256u];
-                wait_head = (wait_head + 1u) & (kFifo - 1u);
-                w--;
-                if (__uint_as_float(e.y) < best.t) {
-                    const float4* t = reinterpret_cast<const float4*>(leaf_bytes + e.x * 128u);
-                    const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
-                    const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
-                    Hit h0, h1;
-                    intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
-                    check_hit(h0, tmin_r, tmax_r, ci0, best, best_ci);
-                    if (ci1 != 0xffffffffu) check_hit(h1, tmin_r, tmax_r, ci1, best, best_ci);
-                }
-            }
-        }
-
-        // 4. a finished ray leaves its closest hit behind and frees the lane
-        if (w == kOver) {
-            hit_records[ray] = make_float4(best.t, best.u, best.v, best.w);
-            hit_ci[ray] = best_ci;
-            w = kIdle;
-        }
-    }
-}
 
 // ---- two levels per step: the walk on the four-grandchildren records ----
 //
@@ -789,6 +628,11 @@ __global__ __launch_bounds__(256) void k_traverse_lean(TraceParams p, const floa
 // testing the grandchildren of a child that fails finds nothing. Boxes are tested earlier than in the reference's
 // walk, i.e. against a closest hit that can only be larger, which adds visits but no result: every leaf still goes
 // through the in-order list and its delayed comparison (see k_traverse).
+// A box is entered if !(tfar < max(tnear, lim)) && tnear != 1e30 && tnear < closest, with lim = tmin if tmin > 0, else
+// the smallest positive float: "tfar <= 0 || tfar < tmin" of the reference's slab test (shader/CS_TraceRays.hlsl:81-97)
+// is "tfar < lim" for every float, and its "tnear > tmax" never holds where tnear < closest <= tmax does. A missing
+// node (a box of NaNs) fails "tnear < closest". Byte offsets into the record and leaf arrays are 32-bit: the launcher
+// uses this kernel only below 4 GiB each.
 // Noted nodes: one nibble per step taken down; bit j of the lowest nibble = slot (h & ~3) | j waits, in order.
 // A hierarchy with an odd number of levels below the trunk starts with the trunk's two children (pair record 1).
 __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const float4* __restrict__ rays, const float4* __restrict__ nodes,
@@ -1087,12 +931,9 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     int rc = rt_set_device(dev);
     if (rc) return rc;
 
-    // tuning knobs (read once): GPURT_TRACE_KERNEL=simple selects the one-thread-per-ray kernel, =wave the
-    // persistent kernel's first form (the one the counting variant is built from), =lean its lean form;
-    // the default walks two levels per step
-    static const bool simple_kernel = [] { const char* v = std::getenv("GPURT_TRACE_KERNEL"); return v && !std::strcmp(v, "simple"); }();
-    static const bool quad_kernel = [] { const char* v = std::getenv("GPURT_TRACE_KERNEL"); return !v || !*v || !std::strcmp(v, "quad"); }();
-    static const bool lean_kernel = [] { const char* v = std::getenv("GPURT_TRACE_KERNEL"); return !(v && !std::strcmp(v, "wave")); }();
+    // the traversal kernel is a device setting (rt_device_set_trace_kernel); the other knobs are read once
+    const bool simple_kernel = dev->trace_kernel == RT_TRACE_KERNEL_SIMPLE;
+    const bool quad_kernel = dev->trace_kernel == RT_TRACE_KERNEL_QUAD;
     static const uint32_t leaf_threshold = env_u32("GPURT_LEAF_THRESHOLD", 12u);
     static const uint32_t blocks_per_cu = env_u32("GPURT_BLOCKS_PER_CU", 3u);
     static const uint32_t sort_rays = env_u32("GPURT_SORT_RAYS", 1u);
@@ -1208,15 +1049,12 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         timing = dev->timing_events + 2u * dev->timing_count++;
         RT_HIP(hipEventRecord(timing[0], s));
     }
-    // the lean kernel addresses pairs and leaves with 32-bit byte offsets
-    const bool lean_fits = rt_aligned_node_slots(&p.lv) * sizeof(rt_aabb) <= 0xffffffffull && (size_t)p.lv.n[0] * 128u <= 0xffffffffull;
+    // k_traverse_quad addresses its records and the leaves with 32-bit byte offsets
+    const bool offsets_fit = rt_aligned_node_slots(&p.lv) * sizeof(rt_aabb) <= 0xffffffffull && (size_t)p.lv.n[0] * 128u <= 0xffffffffull;
     if (stats) RT_LAUNCH_TRAVERSE(true);
-    else if (quad_kernel && lean_fits && p.lv.count >= 3u && quads)
+    else if (quad_kernel && offsets_fit && p.lv.count >= 3u && quads)
         hipLaunchKernelGGL(k_traverse_quad, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in, nodes, pairs, quads,
                            st, dev->hit_records, dev->hit_ci, dev->queue_counter, order);
-    else if (lean_kernel && lean_fits)
-        hipLaunchKernelGGL(k_traverse_lean, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in, nodes, pairs, st,
-                           dev->hit_records, dev->hit_ci, dev->queue_counter, order);
     else RT_LAUNCH_TRAVERSE(false);
 #undef RT_LAUNCH_TRAVERSE
     if (timing) RT_HIP(hipEventRecord(timing[1], s));
@@ -1233,6 +1071,12 @@ extern "C" {
 int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats) {
     if (!dev || (stats && stats->bytes < 32u)) return RT_ERR_INVALID_ARGUMENT;
     dev->trace_stats = stats ? (unsigned long long*)stats->ptr : nullptr;
+    return RT_OK;
+}
+
+int rt_device_set_trace_kernel(rt_device* dev, int kernel) {
+    if (!dev || kernel < RT_TRACE_KERNEL_QUAD || kernel > RT_TRACE_KERNEL_SIMPLE) return RT_ERR_INVALID_ARGUMENT;
+    dev->trace_kernel = kernel;
     return RT_OK;
 }
 

@@ -84,6 +84,15 @@ const char* rt_error_string(int code);
  * {box tests, triangle tests, rays that hit, rays} as four uint64 to it (a slower kernel variant); NULL turns
  * it off. The counts fix the algorithmic bytes per ray of a workload. */
 int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats);
+/* Which traversal kernel rt_trace_rays / rt_trace_rays_accel launch (no counterpart in the reference; results are
+ * identical): QUAD (default) walks two levels of the hierarchy per step on 128-byte records, WAVE one level per step
+ * (also used for hierarchies of fewer than three levels and while counters are on), SIMPLE is one thread per ray
+ * through traversal and shading. The environment variable GPURT_TRACE_KERNEL = quad | wave | simple sets the
+ * initial choice of a new device. */
+#define RT_TRACE_KERNEL_QUAD 0
+#define RT_TRACE_KERNEL_WAVE 1
+#define RT_TRACE_KERNEL_SIMPLE 2
+int rt_device_set_trace_kernel(rt_device* dev, int kernel);
 /* Instrumentation (no counterpart in the reference): while enabled, every trace launch brackets its traversal
  * kernel with a pair of events on the device's stream. rt_device_traverse_timing waits for the pairs recorded
  * so far, returns the sum of their durations and their number, and forgets them. */

@@ -200,8 +200,13 @@ def test_camera_rays_match_oracle(device, oracle, w, h, rpp, dof):
         b.free()
 
 
-def _render_both(device, oracle, sc, w, h, calls, rpp=1, depth=3, use_bvh=True, use_accel=True, dof=0.0):
+KERNEL_QUAD, KERNEL_WAVE, KERNEL_SIMPLE = 0, 1, 2      # RT_TRACE_KERNEL_*
+
+
+def _render_both(device, oracle, sc, w, h, calls, rpp=1, depth=3, use_bvh=True, use_accel=True, dof=0.0, kernel=KERNEL_QUAD):
+    from gpuraytracer_amd import capi
     from gpuraytracer_amd.pipeline import Pipeline
+    capi.check(device.lib.rt_device_set_trace_kernel(device.handle, kernel), "rt_device_set_trace_kernel")
     cam = sc["camera"]
     iv, ip = oracle.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], w / h, cam["near_z"], cam["far_z"])
     ncycles = (calls + depth - 1) // depth
@@ -211,7 +216,10 @@ def _render_both(device, oracle, sc, w, h, calls, rpp=1, depth=3, use_bvh=True, 
     gp = Pipeline(device, sc, w, h, iv, ip, rpp=rpp, depth=depth, dof=dof, use_bvh=use_bvh, use_accel=use_accel,
                   raygen_seeds=lambda: next(ri), trace_seeds=lambda: next(ti))
     op = oracle.Pipeline(sc, w, h, rpp=rpp, depth=depth, dof=dof, use_bvh=use_bvh, seed_raygen=1, seed_trace=2)
-    gp.render(calls)
+    try:
+        gp.render(calls)
+    finally:
+        device.lib.rt_device_set_trace_kernel(device.handle, KERNEL_QUAD)
     op.render(calls)
     out = (gp.output_image(), op.output(), gp.result_image(), op.result(),
            gp.emitted.download(np.float32, 4 * w * h * rpp).reshape(-1, 4), op.emitted(),
@@ -247,15 +255,31 @@ def test_traced_images_match_oracle(device, oracle, n, w, h, calls, use_accel):
 
 
 @pytest.mark.parametrize("n", [3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 1023, 1025, 2049])
-@pytest.mark.parametrize("use_accel", [True, False])
-def test_small_and_odd_triangle_counts_trace_exactly(device, oracle, n, use_accel):
+@pytest.mark.parametrize("use_accel,kernel", [(True, KERNEL_QUAD), (False, KERNEL_QUAD), (True, KERNEL_WAVE)])
+def test_small_and_odd_triangle_counts_trace_exactly(device, oracle, n, use_accel, kernel):
     """Every shape of the balanced hierarchy near its corner cases: two leaves, only children on several levels,
     counts just below, at and above powers of two. Rays that miss everything leave their pixel untouched."""
     sc = _small_scene(n, seed=100 + n)
-    g = _render_both(device, oracle, sc, 48, 32, 4, depth=2, use_accel=use_accel)
+    g = _render_both(device, oracle, sc, 48, 32, 4, depth=2, use_accel=use_accel, kernel=kernel)
     for name, a, b in (("tone-mapped", g[0], g[1]), ("result", g[2], g[3]), ("emitted", g[4], g[5]), ("rays", g[6], g[7])):
         assert a.view(np.uint32).tobytes() == b.view(np.uint32).tobytes(), "%s differs at %d triangles" % (name, n)
     assert g[8]["rays_hit"] > 0, "some ray must hit"
+
+
+@pytest.mark.parametrize("kernel", [KERNEL_QUAD, KERNEL_WAVE, KERNEL_SIMPLE])
+@pytest.mark.parametrize("n", [20000, 40001])
+def test_every_trace_kernel_gives_the_oracle_image(device, oracle, kernel, n):
+    """The three traversal kernels (two levels per step, one level per step, one thread per ray) produce the same
+    buffers, bit for bit; 20000 and 40001 triangles have an even and an odd number of levels below the trunk."""
+    g = _render_both(device, oracle, _scene(n), 128, 72, 6, kernel=kernel)
+    for name, a, b in (("tone-mapped", g[0], g[1]), ("result", g[2], g[3]), ("emitted", g[4], g[5]), ("rays", g[6], g[7])):
+        assert a.view(np.uint32).tobytes() == b.view(np.uint32).tobytes(), "%s differs with kernel %d" % (name, kernel)
+
+
+def test_invalid_trace_kernel_is_rejected(device):
+    from gpuraytracer_amd import capi
+    assert device.lib.rt_device_set_trace_kernel(device.handle, 3) == capi.RT_ERR_INVALID_ARGUMENT
+    assert device.lib.rt_device_set_trace_kernel(device.handle, -1) == capi.RT_ERR_INVALID_ARGUMENT
 
 
 def test_traverse_timing_reports_every_launch(device, oracle):
