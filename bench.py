@@ -33,6 +33,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak
 BUILD_BYTES_PER_TRIANGLE = 252  # Morton 56 + sort 80 + leaves 68 + upper levels 48 (reference data layout)
 
+# HBM-side bytes of ONE k_traverse_quad launch of the default workload on one GPU, from the hardware-counter passes
+# committed as profiles/r1_c3_quad_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in runs of their
+# own, kilobytes -> bytes): the kernel's reads past L2 are gathers of 64-byte requests, for which FETCH_SIZE counts
+# the bytes exactly (scripts/calib_fetch.hip; the doubling the microarchitecture guide prescribes applies to wide
+# streaming reads, which this kernel does not issue). Counters cannot be read inside a timed run, so the figure is
+# carried here and reported only for the configuration it was measured on.
+MEASURED_TRAFFIC = {("c3", 1): {"fetch": 215262213.5e3, "write": 702763.0e3}}
+
 WORKLOADS = {
     # name: (triangles, width, height, rays/pixel, bounces, description)
     "c3": (1000000, 3840, 2160, 1, 4, "C3: synthetic 1M-triangle scene, 3840x2160, 1 ray/pixel, 4 bounces, LBVH rebuilt every frame"),
@@ -196,6 +204,9 @@ def main():
     achieved = bytes_per_launch / avg_trace_s / 1e9
     avg_build_ms = float(np.mean(build_ms))
 
+    tkey = (args.workload, world)
+    plain = not (args.triangles or args.width or args.height or args.band or args.dynamic) and args.scaling == "weak"
+    traffic = MEASURED_TRAFFIC.get(tkey) if plain and os.environ.get("GPURT_TRACE_KERNEL", "quad") in ("", "quad") else None
     out = {
         "metric": "Mrays/sec", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
@@ -207,8 +218,13 @@ def main():
                    "triangles": ntri, "width": width, "height": height, "rays_per_pixel": rpp, "bounces": depth,
                    "parallelism": "image rows dealt to %d GPU(s) in turn, replicated scene + per-GPU rebuild, gather to rank 0" % world},
         "lbvh_build_ms": round(avg_build_ms, 4),
-        "roofline": {"kernel": "k_traverse", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "roofline": {"kernel": "k_traverse_quad", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                     "traffic": int(traffic["fetch"] + traffic["write"]) if traffic else None,
+                     "traffic_source": "profiles/r1_c3_quad_pmc_summary.txt (FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
+                     "note": "algorithmic bytes are those of the reference's data layout (32 B per box test, 48 B per triangle "
+                             "test); most of them are served by L1/L2, so achieved may exceed the HBM peak - "
+                             "traffic is what actually crossed the memory side",
                      "avg_launch_ms": round(avg_trace_s * 1e3, 4), "launches_timed": int(kernel_launches.value),
                      "avg_trace_call_ms": round(avg_trace_call_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                      "rays_per_launch": local_rays, "box_tests_per_ray": round(nodes / max(counted, 1), 2),
