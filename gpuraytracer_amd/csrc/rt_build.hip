@@ -427,6 +427,39 @@ __device__ __forceinline__ void store_pair_half(rt_aabb* pairs, uint32_t pair_sl
     p[6 + child] = a.mx[0]; p[8 + child] = a.mx[1]; p[10 + child] = a.mx[2];
     p[12 + 2u * child] = __uint_as_float(a0); p[13 + 2u * child] = __uint_as_float(a1);
 }
+// The four-grandchildren records (rt_quad_records) are written along with the pair records: the pair record of the
+// children of node c (index ci of level k + 1) is one half of the 128-byte record of c's parent, which exists where
+// level k + 2 does and k is even. The last node of a level with an odd count has no sibling: its parent's second
+// half is NaNs.
+__device__ __forceinline__ float4* quad_half(float4* quads, const rt_levels& lv, uint32_t k, uint32_t ci) {
+    const uint32_t c = lv.aoff[k + 1u] + ci;                   // slot of node c
+    return quads + 8 * (size_t)(c >> 1) + 3u * (c & 1u);
+}
+__device__ __forceinline__ bool quad_level(const rt_levels& lv, uint32_t k) { return !(k & 1u) && k + 2u < lv.count; }
+__device__ __forceinline__ void store_quad_pair(float4* quads, const rt_levels& lv, uint32_t k, uint32_t ci, const Box& a,
+                                                const Box& b) {
+    float4* o = quad_half(quads, lv, k, ci);
+    o[0] = make_float4(a.mn[0], b.mn[0], a.mn[1], b.mn[1]);
+    o[1] = make_float4(a.mn[2], b.mn[2], a.mx[0], b.mx[0]);
+    o[2] = make_float4(a.mx[1], b.mx[1], a.mx[2], b.mx[2]);
+    if (!(ci & 1u) && ci + 1u >= lv.n[k + 1u]) {
+        const float nan = __uint_as_float(0x7fc00000u);
+        o[3] = o[4] = o[5] = make_float4(nan, nan, nan, nan);
+    }
+}
+// one node's half of its pair (where the sibling is produced by another workgroup); child = 0 or 1
+__device__ __forceinline__ void store_quad_pair_half(float4* quads, const rt_levels& lv, uint32_t k, uint32_t ci, uint32_t child,
+                                                     const Box& a) {
+    float4* o = quad_half(quads, lv, k, ci);
+    float* p = reinterpret_cast<float*>(o);
+    p[0 + child] = a.mn[0]; p[2 + child] = a.mn[1]; p[4 + child] = a.mn[2];
+    p[6 + child] = a.mx[0]; p[8 + child] = a.mx[1]; p[10 + child] = a.mx[2];
+    if (child == 0u && !(ci & 1u) && ci + 1u >= lv.n[k + 1u]) {
+        const float nan = __uint_as_float(0x7fc00000u);
+        o[3] = o[4] = o[5] = make_float4(nan, nan, nan, nan);
+    }
+}
+
 // the next lane's box, or - where the next node does not exist - a box of NaNs, which no box built from
 // vertices can be (min/max drop NaN operands); the walk recognises a missing child by it
 __device__ __forceinline__ Box next_lane_box(const Box& b, bool exists) {
@@ -445,7 +478,7 @@ __device__ __forceinline__ Box next_lane_box(const Box& b, bool exists) {
 // LDS slot order (slot s <-> node blockIdx.x*256 + s of level k0). Same arithmetic as
 // shader/CS_BVHBuild.hlsl:28-47: min/max union, links (first child, second child or 0xffffffff).
 __device__ __forceinline__ void upsweep_block(Box mine, uint32_t k0, const rt_levels& lv, rt_aabb* __restrict__ nodes,
-                                              rt_aabb* __restrict__ pairs, float (*s_box)[6]) {
+                                              rt_aabb* __restrict__ pairs, float4* __restrict__ quads, float (*s_box)[6]) {
     const uint32_t tid = threadIdx.x;
     uint32_t cnt = 256u;
     uint32_t k = k0;
@@ -478,13 +511,19 @@ __device__ __forceinline__ void upsweep_block(Box mine, uint32_t k0, const rt_le
             if (cnt >= 2u) {
                 const Box other = next_lane_box(mine, gi + 1u < lv.n[k]);
                 const uint32_t o0 = __shfl_down(l0, 1, 64), o1 = __shfl_down(l1, 1, 64);
-                if (have && !(gi & 1u)) store_pair(pairs, lv.aoff[k] + gi, mine, other, l0, l1, o0, o1);
+                if (have && !(gi & 1u)) {
+                    store_pair(pairs, lv.aoff[k] + gi, mine, other, l0, l1, o0, o1);
+                    if (quads && quad_level(lv, k)) store_quad_pair(quads, lv, k, gi >> 1, mine, other);
+                }
             } else if (have) {
+                const bool quad = quads && quad_level(lv, k);
                 store_pair_half(pairs, lv.aoff[k] + (gi & ~1u), gi & 1u, mine, l0, l1);
+                if (quad) store_quad_pair_half(quads, lv, k, gi >> 1, gi & 1u, mine);
                 if (!(gi & 1u) && gi + 1u >= lv.n[k]) {        // an only child: mark the other half as missing
                     Box none;
                     for (int a = 0; a < 3; a++) none.mn[a] = none.mx[a] = __uint_as_float(0x7fc00000u);
                     store_pair_half(pairs, lv.aoff[k] + gi, 1u, none, 0xffffffffu, 0xffffffffu);
+                    if (quad) store_quad_pair_half(quads, lv, k, gi >> 1, 1u, none);
                 }
             }
         }
@@ -498,7 +537,7 @@ template <bool PACKED, bool FUSED>
 __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv, const uint32_t* __restrict__ sorted,
                                                 const uint32_t* __restrict__ indices, const rt_vertex* __restrict__ verts,
                                                 const float4* __restrict__ tris, float4* __restrict__ sorted_tris,
-                                                rt_aabb* __restrict__ nodes, rt_aabb* __restrict__ pairs) {
+                                                rt_aabb* __restrict__ nodes, rt_aabb* __restrict__ pairs, float4* __restrict__ quads) {
     __shared__ float s_box[256][6];
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t leaves = (num_prims + 1u) / 2u;
@@ -537,15 +576,17 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
     if (PACKED && pairs) {                             // same for the whole grid
         const Box other = next_lane_box(b, g + 1u < leaves);
         const uint32_t o0 = __shfl_down(ci0, 1, 64), o1 = __shfl_down(ci1, 1, 64);
-        if (g < leaves && !(g & 1u))
+        if (g < leaves && !(g & 1u)) {
             store_pair(pairs, lv.aoff[0] + g, b, other, ci0 | 0x80000000u, ci1 | 0x80000000u, o0 | 0x80000000u, o1 | 0x80000000u);
+            if (quads && quad_level(lv, 0u)) store_quad_pair(quads, lv, 0u, g >> 1, b, other);
+        }
     }
-    if (FUSED) upsweep_block(b, 0u, lv, nodes, pairs, s_box);
+    if (FUSED) upsweep_block(b, 0u, lv, nodes, pairs, quads, s_box);
 }
 
 // continues the up-sweep from level k0 (already in memory), eight levels per launch
 __global__ __launch_bounds__(256) void k_upsweep(uint32_t k0, rt_levels lv, rt_aabb* __restrict__ nodes,
-                                                 rt_aabb* __restrict__ pairs) {
+                                                 rt_aabb* __restrict__ pairs, float4* __restrict__ quads) {
     __shared__ float s_box[256][6];
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     Box b;
@@ -556,7 +597,7 @@ __global__ __launch_bounds__(256) void k_upsweep(uint32_t k0, rt_levels lv, rt_a
         float4 lo = p[0], hi = p[1];
         b.mn[0] = lo.x; b.mn[1] = lo.y; b.mn[2] = lo.z; b.mx[0] = lo.w; b.mx[1] = hi.x; b.mx[2] = hi.y;
     }
-    upsweep_block(b, k0, lv, nodes, pairs, s_box);
+    upsweep_block(b, k0, lv, nodes, pairs, quads, s_box);
 }
 
 // one level, reference parameters (shader/CS_BVHBuild.hlsl:25-48)
@@ -786,7 +827,7 @@ int rt_bvh_build_leaves(rt_device* dev, const rt_bvh_info* info, const rt_buffer
     lv.count = 0;
     hipLaunchKernelGGL((k_leaves<false, false>), dim3(div_up(leaves, 256u)), dim3(256), 0, dev->stream, n, lv,
                        (const uint32_t*)morton_codes->ptr, (const uint32_t*)indices->ptr, (const rt_vertex*)vertices->ptr,
-                       (const float4*)nullptr, (float4*)nullptr, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr);
+                       (const float4*)nullptr, (float4*)nullptr, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, (float4*)nullptr);
     return rt_launch_status();
 }
 
@@ -965,13 +1006,10 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     if (rc) return rc;
     const uint32_t leaves = lv.n[0];
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)src,
-                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, a->pairs);
+                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, a->pairs,
+                       a->quads);
     for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
-        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, a->pairs);
-    if (lv.count >= 3u) {
-        const uint32_t slots = (uint32_t)rt_quad_records(&lv);
-        hipLaunchKernelGGL(k_quads_from_pairs, dim3(div_up(slots, 256u)), dim3(256), 0, s, lv, slots, (const float4*)a->pairs, a->quads);
-    }
+        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, a->pairs, a->quads);
     if (morton_codes)
         hipLaunchKernelGGL(k_expand_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, n, src, (uint4*)morton_codes->ptr);
     return rt_launch_status();
