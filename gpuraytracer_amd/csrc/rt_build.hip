@@ -405,6 +405,8 @@ __device__ __forceinline__ void store_leaf_triangles(float4* sorted_tris, uint32
     o[2] = make_float4(p[1][1], p[4][1], p[1][2], p[4][2]);
     o[3] = make_float4(p[2][0], p[5][0], p[2][1], p[5][1]);
     o[4] = make_float4(p[2][2], p[5][2], __uint_as_float(ci0), __uint_as_float(ci1));
+    // the rest of the line is written as well: whole 128-byte lines go to memory faster than 80 bytes of each
+    o[5] = o[6] = o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // The accel's private copy of the hierarchy holds sibling pairs: children 2j and 2j+1 of every node share one

@@ -45,6 +45,7 @@ struct TraceParams {
     uint32_t num_materials, num_textures;
     uint32_t leaf_threshold;
     uint32_t queue_chunk;      // slots per queue of the persistent traversal kernel (a multiple of the dealt block)
+    uint32_t refill_threshold; // lanes that must be free before a wave of k_traverse_quad takes new rays
     uint32_t deal_shift;       // blocks of 2^deal_shift consecutive positions of the ray order are dealt to the queues in turn
     rt_levels lv;
 };
@@ -665,8 +666,10 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
 
     for (;;) {
         // 1. refill: every lane without a ray takes the next index; one atomic per wave (see k_traverse)
+        //    A refill stalls the whole wave for an atomic and two dependent loads, so it waits until several lanes are
+        //    free, unless nobody could walk meanwhile.
         const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(w == kIdle);
-        if (need_mask) {
+        if (need_mask && ((uint32_t)__popcll(need_mask) >= p.refill_threshold || !__builtin_amdgcn_ballot_w64(w <= kFifo - 4u))) {
             if (queues_tried >= 8u) {
                 if (w == kIdle) w = kDry;
             } else {
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
             waiting_mask = __builtin_amdgcn_ballot_w64((w & 15u) != 0u);
             walking_mask = __builtin_amdgcn_ballot_w64(w <= kFifo - 4u);
             if (!walking_mask || (uint32_t)__popcll(waiting_mask) >= p.leaf_threshold) break;
-            if (__builtin_amdgcn_ballot_w64(w == kOver)) break;
+            if ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(w >= kOver && w != kDry)) >= p.refill_threshold) break;
         }
 
         // 3. triangle round once enough lanes have a leaf waiting (or nobody can walk any more)
@@ -954,6 +957,8 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     p.leaf_threshold = leaf_threshold < 1u ? 1u : (leaf_threshold > 64u ? 64u : leaf_threshold);
     static const uint32_t deal_shift_env = env_u32("GPURT_DEAL_SHIFT", 6u);
     static const uint32_t cost_major_bits = env_u32("GPURT_COST_BITS", 6u) > 6u ? 6u : env_u32("GPURT_COST_BITS", 6u);
+    static const uint32_t refill_threshold = env_u32("GPURT_REFILL_THRESHOLD", 16u);
+    p.refill_threshold = refill_threshold < 1u ? 1u : (refill_threshold > 64u ? 64u : refill_threshold);
     p.deal_shift = deal_shift_env < 6u ? 6u : (deal_shift_env > 20u ? 20u : deal_shift_env);
     const uint32_t deal_block = 1u << p.deal_shift;
     p.queue_chunk = ((((nr + deal_block - 1u) / deal_block) + 7u) / 8u) * deal_block;      // whole blocks, dealt to the eight queues in turn
