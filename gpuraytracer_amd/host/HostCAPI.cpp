@@ -21,6 +21,7 @@ struct rth_settings
 	float cam_position[3], cam_focus[3], cam_up[3];
 	int32_t rebuild_every_cycle, fused_build;
 	uint32_t seed_raygen, seed_trace;
+	int32_t dynamic_scene;
 };
 
 void rth_camera_matrices(const float* position, const float* focus, const float* up, float fov, float aspect, float near_z, float far_z,
@@ -114,6 +115,7 @@ static Settings ToSettings(const rth_settings* s)
 	r.RebuildBVHEveryCycle = s->rebuild_every_cycle != 0;
 	r.FusedBuild = s->fused_build != 0;
 	r.SeedRayGen = s->seed_raygen; r.SeedTrace = s->seed_trace;
+	r.DynamicScene = s->dynamic_scene != 0;
 	return r;
 }
 
@@ -140,6 +142,9 @@ int rth_pipeline_read_result(RaytracerPipeline* p, float* pixels) { return p->Re
 rt_buffer* rth_pipeline_bvh(RaytracerPipeline* p) { return p->GetBVH(); }
 rt_buffer* rth_pipeline_morton(RaytracerPipeline* p) { return p->GetMortonCodes(); }
 rt_buffer* rth_pipeline_slot(RaytracerPipeline* p, uint32_t slot) { return slot < 8 ? p->GetDescriptorHeap()->Slots[slot] : nullptr; }
+int rth_pipeline_save_state(RaytracerPipeline* p, const char* path) { return p->SaveState(path) ? 1 : 0; }
+int rth_pipeline_load_state(RaytracerPipeline* p, const char* path) { return p->LoadState(path) ? 1 : 0; }
+uint32_t rth_pipeline_num_samples(RaytracerPipeline* p) { return p->GetNumSamples(); }
 void rth_pipeline_destroy(RaytracerPipeline* p) { delete p; }
 
 int rth_write_ppm(const char* path, const float* pixels, uint32_t w, uint32_t h) { return WriteImagePPM(path, pixels, w, h) ? 1 : 0; }

@@ -4,7 +4,8 @@
 //
 //   rt_headless [--scene file.obj | --synthetic N] [--width W] [--height H] [--rpp R] [--depth D]
 //               [--cycles C] [--no-bvh] [--per-shader-build] [--rebuild] [--camera px py pz fx fy fz]
-//               [--seed S] [--gpu G] [--out image.ppm] [--pfm image.pfm]
+//               [--seed S] [--gpu G] [--out image.ppm] [--pfm image.pfm] [--dynamic]
+//               [--resume state.bin] [--save-state state.bin]
 
 #include <chrono>
 #include <cstdlib>
@@ -21,7 +22,7 @@ using namespace RT::GraphicsAPI;
 int main(int argc, char** argv)
 {
 	Settings rtSettings;
-	std::string sOut = "image.ppm", sPFM;
+	std::string sOut = "image.ppm", sPFM, sResume, sSaveState;
 	uint32_t iSynthetic = 0, iCycles = 1;
 	int iGPU = 0;
 	rtSettings.SeedRayGen = 1;
@@ -43,6 +44,9 @@ int main(int argc, char** argv)
 		else if (!std::strcmp(argv[i], "--gpu")) iGPU = std::atoi(Next());
 		else if (!std::strcmp(argv[i], "--out")) sOut = Next();
 		else if (!std::strcmp(argv[i], "--pfm")) sPFM = Next();
+		else if (!std::strcmp(argv[i], "--dynamic")) rtSettings.DynamicScene = true;
+		else if (!std::strcmp(argv[i], "--resume")) sResume = Next();
+		else if (!std::strcmp(argv[i], "--save-state")) sSaveState = Next();
 		else if (!std::strcmp(argv[i], "--camera"))
 		{
 			for (int k = 0; k < 3; k++) rtSettings.CameraPosition[k] = (float)std::atof(Next());
@@ -76,6 +80,11 @@ int main(int argc, char** argv)
 		return 1;
 	}
 	std::cout << "Raytracing pipeline was initialized successfully\n";
+	if (!sResume.empty())
+	{
+		if (!rtRenderer.LoadState(sResume)) { std::cout << "Error while reading " << sResume << "\n"; return 1; }
+		std::cout << "Resumed at " << rtRenderer.GetNumSamples() - 1 << " accumulated sample cycles\n";
+	}
 
 	const auto stdStart = std::chrono::steady_clock::now();
 	uint64_t iCalls = 0;
@@ -93,6 +102,7 @@ int main(int argc, char** argv)
 	const double fRays = (double)iCalls * rtSettings.WindowWidth * rtSettings.WindowHeight * rtSettings.MaxRaysPerPixel;
 	std::cout << iTriangles << " triangles, " << iCalls << " bounces in " << fSeconds << " s: " << fRays / fSeconds * 1e-6 << " Mrays/s\n";
 
+	if (!sSaveState.empty() && !rtRenderer.SaveState(sSaveState)) { std::cout << "Error while writing " << sSaveState << "\n"; return 1; }
 	std::vector<float> stdPixels((size_t)rtSettings.WindowWidth * rtSettings.WindowHeight * 4);
 	if (!rtRenderer.ReadOutput(stdPixels.data())) { std::cout << "Error while reading the image\n"; return 1; }
 	if (!sOut.empty() && !WriteImagePPM(sOut, stdPixels.data(), rtSettings.WindowWidth, rtSettings.WindowHeight)) { std::cout << "Error while writing " << sOut << "\n"; return 1; }

@@ -212,6 +212,12 @@ namespace RT::GraphicsAPI
 		return true;
 	}
 
+	void SortPrimitives::SetSceneAABB(AABB rtSceneAABB)
+	{
+		m_rtMortonCodeInfoData.scene_min[0] = rtSceneAABB.Min.x; m_rtMortonCodeInfoData.scene_min[1] = rtSceneAABB.Min.y; m_rtMortonCodeInfoData.scene_min[2] = rtSceneAABB.Min.z;
+		m_rtMortonCodeInfoData.scene_max[0] = rtSceneAABB.Max.x; m_rtMortonCodeInfoData.scene_max[1] = rtSceneAABB.Max.y; m_rtMortonCodeInfoData.scene_max[2] = rtSceneAABB.Max.z;
+	}
+
 	bool SortPrimitives::Sort(RaytracerMesh* rtMesh)
 	{
 		const rt_buffer* rtIndices = nullptr;
@@ -290,6 +296,16 @@ namespace RT::GraphicsAPI
 		m_rtBVHInfoData.num_children = 2;
 		m_rtBVHInfoData.current_index = 0;
 		return rt_bvh_build(m_rtDevice, &m_rtBVHInfoData, m_rtBVHBuffer) == RT_OK;
+	}
+
+	bool BuildBVH::BuildFusedMoved(RaytracerMesh* rtMesh, rt_buffer* rtBounds, rt_buffer* rtMortonCodes)
+	{
+		const rt_buffer* rtIndices = nullptr;
+		const rt_buffer* rtVertices = nullptr;
+		rtMesh->Bind(&rtIndices, &rtVertices);
+		if (!m_rtAccel && rt_accel_create(m_rtDevice, m_iNumPrimitives, &m_rtAccel) != RT_OK) return false;
+		if (rt_accel_pack_bounds(m_rtAccel, m_iNumPrimitives, rtIndices, rtVertices, rtBounds) != RT_OK) return false;
+		return rt_accel_build_device_bounds(m_rtAccel, rtBounds, m_rtBVHBuffer, rtMortonCodes) == RT_OK;
 	}
 
 	bool BuildBVH::BuildFused(RaytracerMesh* rtMesh, AABB rtSceneAABB, rt_buffer* rtMortonCodes)
@@ -461,7 +477,10 @@ namespace RT::GraphicsAPI
 		m_rtUAVDescriptorHeap(nullptr),
 		m_rtSceneAABB(),
 		m_bBuildBVH(true),
-		m_iIteration(0)
+		m_iIteration(0),
+		m_rtBaseVertexBuffer(nullptr),
+		m_rtBoundsBuffer(nullptr),
+		m_iFrame(0)
 	{
 	}
 
@@ -474,6 +493,8 @@ namespace RT::GraphicsAPI
 		delete m_rtTraceRays;
 		delete m_rtImageGeneration;
 		delete m_rtUAVDescriptorHeap;
+		if (m_rtBaseVertexBuffer) rt_buffer_free(m_rtBaseVertexBuffer);
+		if (m_rtBoundsBuffer) rt_buffer_free(m_rtBoundsBuffer);
 	}
 
 	bool RaytracerPipeline::Initialize(rt_device* rtDevice, MeshInfo rtMeshData, const Settings* rtSettings)
@@ -483,6 +504,17 @@ namespace RT::GraphicsAPI
 		if (rtSettings) m_rtSettings = *rtSettings;
 		if (m_rtSettings.MaxRayDepth == 0 || m_rtSettings.MaxRaysPerPixel == 0) return false;
 		m_rtSceneAABB = rtMeshData.SceneAABB;
+		if (m_rtSettings.DynamicScene)
+		{
+			//the moving workload is defined on triangle soups (vertices 3i .. 3i + 2 = triangle i), which is what the loader
+			//and the generator produce; it keeps the mesh as loaded beside the moved copy the stages bind
+			if (!m_rtSettings.UseBVH || rtMeshData.VertexCount != rtMeshData.IndexCount) return false;
+			const size_t iBytes = (size_t)rtMeshData.VertexCount * sizeof(Vertex);
+			if (rt_buffer_alloc(m_rtDevice, iBytes, &m_rtBaseVertexBuffer) != RT_OK) return false;
+			if (rt_buffer_upload(m_rtBaseVertexBuffer, rtMeshData.Vertices, iBytes, 0) != RT_OK) return false;
+			if (rt_buffer_alloc(m_rtDevice, 32, &m_rtBoundsBuffer) != RT_OK) return false;
+			m_rtSettings.RebuildBVHEveryCycle = true;
+		}
 
 		m_rtUAVDescriptorHeap = new DescriptorHeap();
 
@@ -513,6 +545,26 @@ namespace RT::GraphicsAPI
 		return true;
 	}
 
+	//DynamicScene: the triangles at their places of the next frame, in the vertex buffer the stages bind
+	bool RaytracerPipeline::MoveScene()
+	{
+		const rt_buffer* rtIndices = nullptr;
+		const rt_buffer* rtVertices = nullptr;
+		m_rtTraceRays->GetMesh()->Bind(&rtIndices, &rtVertices);
+		const uint32_t iNumPrimitives = (uint32_t)(m_rtTraceRays->GetMesh()->GetIndexCount() / 3);
+		if (rt_synthetic_animate(m_rtDevice, iNumPrimitives, m_iFrame++, m_rtBaseVertexBuffer, const_cast<rt_buffer*>(rtVertices)) != RT_OK)
+			return false;
+		if (m_rtSettings.FusedBuild) return true;
+		//the per-shader launchers take the scene bounds from the host, as the reference's constant buffer does
+		float pBounds[8];
+		if (rt_scene_bounds(m_rtDevice, iNumPrimitives, rtIndices, rtVertices, m_rtBoundsBuffer) != RT_OK) return false;
+		if (rt_buffer_readback(m_rtBoundsBuffer, pBounds, sizeof(pBounds), 0) != RT_OK) return false;
+		m_rtSceneAABB.Min = { pBounds[0], pBounds[1], pBounds[2] };
+		m_rtSceneAABB.Max = { pBounds[4], pBounds[5], pBounds[6] };
+		m_rtSortPrimitives->SetSceneAABB(m_rtSceneAABB);
+		return true;
+	}
+
 	//one call = one bounce for every ray in flight
 	bool RaytracerPipeline::Render()
 	{
@@ -521,7 +573,12 @@ namespace RT::GraphicsAPI
 			//the reference builds once; RebuildBVHEveryCycle repeats the build whenever new camera rays start
 			if (m_bBuildBVH || (m_rtSettings.RebuildBVHEveryCycle && m_iIteration == 0))
 			{
-				if (m_rtSettings.FusedBuild)
+				if (m_rtSettings.DynamicScene && !MoveScene()) return false;
+				if (m_rtSettings.DynamicScene && m_rtSettings.FusedBuild)
+				{
+					if (!(m_rtBuildBVH->BuildFusedMoved(m_rtTraceRays->GetMesh(), m_rtBoundsBuffer, m_rtSortPrimitives->GetMortonCodes()))) return false;
+				}
+				else if (m_rtSettings.FusedBuild)
 				{
 					if (!(m_rtBuildBVH->BuildFused(m_rtTraceRays->GetMesh(), m_rtSceneAABB, m_rtSortPrimitives->GetMortonCodes()))) return false;
 				}
@@ -554,6 +611,38 @@ namespace RT::GraphicsAPI
 	{
 		const size_t iBytes = 16 * (size_t)m_rtSettings.WindowWidth * m_rtSettings.WindowHeight;
 		return rt_buffer_readback(m_rtUAVDescriptorHeap->Slots[6], pPixels, iBytes, 0) == RT_OK;
+	}
+
+	//file: "GPURTSTATE1 <width> <height> <samples>\n" followed by width * height float4 (little-endian binary32)
+	bool RaytracerPipeline::SaveState(const std::string& sFileName)
+	{
+		if (m_iIteration != 0) return false;		//only between two sample cycles
+		const size_t iPixels = (size_t)m_rtSettings.WindowWidth * m_rtSettings.WindowHeight;
+		std::vector<float> stdPixels(iPixels * 4);
+		if (!ReadResult(stdPixels.data())) return false;
+		std::ofstream stdFile(sFileName, std::ios::binary);
+		if (!stdFile) return false;
+		stdFile << "GPURTSTATE1 " << m_rtSettings.WindowWidth << " " << m_rtSettings.WindowHeight << " " << m_rtImageGeneration->GetNumSamples() << "\n";
+		stdFile.write((const char*)stdPixels.data(), (std::streamsize)(stdPixels.size() * sizeof(float)));
+		return (bool)stdFile;
+	}
+
+	bool RaytracerPipeline::LoadState(const std::string& sFileName)
+	{
+		if (m_iIteration != 0) return false;
+		std::ifstream stdFile(sFileName, std::ios::binary);
+		if (!stdFile) return false;
+		std::string sMagic;
+		uint32_t iWidth = 0, iHeight = 0, iSamples = 0;
+		stdFile >> sMagic >> iWidth >> iHeight >> iSamples;
+		if (!stdFile || sMagic != "GPURTSTATE1" || stdFile.get() != '\n') return false;
+		if (iWidth != m_rtSettings.WindowWidth || iHeight != m_rtSettings.WindowHeight || iSamples == 0) return false;
+		std::vector<float> stdPixels((size_t)iWidth * iHeight * 4);
+		stdFile.read((char*)stdPixels.data(), (std::streamsize)(stdPixels.size() * sizeof(float)));
+		if (stdFile.gcount() != (std::streamsize)(stdPixels.size() * sizeof(float))) return false;
+		if (rt_buffer_upload(m_rtImageGeneration->GetResultBuffer(), stdPixels.data(), stdPixels.size() * sizeof(float), 0) != RT_OK) return false;
+		m_rtImageGeneration->SetNumSamples(iSamples);
+		return true;
 	}
 
 	bool RaytracerPipeline::ReadResult(float* pPixels)

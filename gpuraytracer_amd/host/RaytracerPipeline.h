@@ -90,6 +90,8 @@ namespace RT::GraphicsAPI
 
 		rt_buffer* GetMortonCodes() { return m_rtMortonCodeBuffer; };
 		const MortonCodeInfo& GetInfo() const { return m_rtMortonCodeInfoData; };
+		//new bounds for a mesh that has moved (the reference computes them once, on load)
+		void SetSceneAABB(AABB rtSceneAABB);
 	};
 
 
@@ -111,6 +113,9 @@ namespace RT::GraphicsAPI
 		bool Build(RaytracerMesh* rtMesh, rt_buffer* rtMortonCodes);
 		//Sort + Build in one fused call (the fast path); rtMortonCodes may be null
 		bool BuildFused(RaytracerMesh* rtMesh, AABB rtSceneAABB, rt_buffer* rtMortonCodes);
+		//the same for a mesh that has moved on the device: gathers the triangles again, leaves their centroid bounds
+		//(8 floats) in rtBounds and builds with them, without a round trip to the host
+		bool BuildFusedMoved(RaytracerMesh* rtMesh, rt_buffer* rtBounds, rt_buffer* rtMortonCodes);
 
 		rt_buffer* GetBVH() { return m_rtBVHBuffer; };
 		rt_accel* GetAccel() { return m_rtAccel; };
@@ -161,6 +166,9 @@ namespace RT::GraphicsAPI
 		bool Render(bool bApplyResults = false);
 
 		uint32_t GetNumSamples() const { return m_rtInfoData.num_samples & 0x7fffffffu; };
+		//restores a sample counter saved between two cycles (checkpoint / resume)
+		void SetNumSamples(uint32_t iNumSamples) { m_rtInfoData.num_samples = iNumSamples & 0x7fffffffu; };
+		rt_buffer* GetResultBuffer() { return m_rtResultBuffer; };
 	};
 
 
@@ -178,6 +186,11 @@ namespace RT::GraphicsAPI
 		AABB					m_rtSceneAABB;
 		bool					m_bBuildBVH;
 		unsigned int			m_iIteration;
+		rt_buffer*				m_rtBaseVertexBuffer;	//DynamicScene: the mesh as loaded
+		rt_buffer*				m_rtBoundsBuffer;		//DynamicScene: centroid bounds of the moved mesh (device)
+		uint32_t				m_iFrame;
+
+		bool MoveScene();
 
 	public:
 		RaytracerPipeline();
@@ -190,6 +203,11 @@ namespace RT::GraphicsAPI
 		//headless output instead of the window: the tone-mapped image and the accumulated mean, Width * Height float4 each
 		bool ReadOutput(float* pPixels);
 		bool ReadResult(float* pPixels);
+		//checkpoint of the accumulation (the reference has none: its state lives in ResultBuffer and NumSamples only):
+		//the running-mean image and the sample counter, written / restored between two sample cycles
+		bool SaveState(const std::string& sFileName);
+		bool LoadState(const std::string& sFileName);
+		uint32_t GetNumSamples() const { return m_rtImageGeneration ? m_rtImageGeneration->GetNumSamples() : 0; };
 		//raw views for tests
 		rt_buffer* GetBVH() { return m_rtBuildBVH ? m_rtBuildBVH->GetBVH() : nullptr; };
 		rt_buffer* GetMortonCodes() { return m_rtSortPrimitives ? m_rtSortPrimitives->GetMortonCodes() : nullptr; };

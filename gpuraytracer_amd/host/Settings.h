@@ -60,6 +60,8 @@ namespace RT
 		//additions of the headless build
 		bool RebuildBVHEveryCycle = false;  //the reference builds once; true = per-frame rebuild
 		bool FusedBuild = true;             //one fused LBVH build instead of one launch per reference dispatch
+		bool DynamicScene = false;          //the synthetic moving workload: before every cycle the triangles are moved on the
+		                                    //device (rt_synthetic_animate), the scene bounds reduced there and the tree rebuilt
 		uint32_t SeedRayGen = 0;            //std::mt19937 seeds of the two host generators; 0 = std::random_device
 		uint32_t SeedTrace = 0;
 	};

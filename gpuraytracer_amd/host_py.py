@@ -16,7 +16,7 @@ class HostSettings(C.Structure):
                 ("aa_spread", C.c_float), ("dof_spread", C.c_float), ("use_bvh", C.c_int32), ("fov", C.c_float),
                 ("near_z", C.c_float), ("far_z", C.c_float), ("cam_position", C.c_float * 3), ("cam_focus", C.c_float * 3),
                 ("cam_up", C.c_float * 3), ("rebuild_every_cycle", C.c_int32), ("fused_build", C.c_int32),
-                ("seed_raygen", C.c_uint32), ("seed_trace", C.c_uint32)]
+                ("seed_raygen", C.c_uint32), ("seed_trace", C.c_uint32), ("dynamic_scene", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -49,6 +49,8 @@ def load():
         "rth_pipeline_render": (C.c_int, [_P, C.c_uint32]),
         "rth_pipeline_read_output": (C.c_int, [_P, _P]), "rth_pipeline_read_result": (C.c_int, [_P, _P]),
         "rth_pipeline_bvh": (_P, [_P]), "rth_pipeline_morton": (_P, [_P]), "rth_pipeline_slot": (_P, [_P, C.c_uint32]),
+        "rth_pipeline_save_state": (C.c_int, [_P, C.c_char_p]), "rth_pipeline_load_state": (C.c_int, [_P, C.c_char_p]),
+        "rth_pipeline_num_samples": (C.c_uint32, [_P]),
         "rth_pipeline_destroy": (None, [_P]),
         "rth_write_ppm": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
         "rth_write_pfm": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
@@ -135,7 +137,7 @@ class HostPipeline:
     """RaytracerPipeline (C++) driven from Python: Initialize once, Render() per bounce."""
 
     def __init__(self, dev, mesh_source, width, height, camera, rpp=1, depth=3, aa=1.5, dof=0.0, use_bvh=True, fused_build=True,
-                 rebuild_every_cycle=False, seed_raygen=1, seed_trace=2):
+                 rebuild_every_cycle=False, seed_raygen=1, seed_trace=2, dynamic=False):
         self.lib = load()
         self.dev = dev
         self.width, self.height = width, height
@@ -155,6 +157,7 @@ class HostPipeline:
             s.cam_up[k] = camera["up"][k]
         s.rebuild_every_cycle, s.fused_build = int(rebuild_every_cycle), int(fused_build)
         s.seed_raygen, s.seed_trace = seed_raygen, seed_trace
+        s.dynamic_scene = int(dynamic)
         self.handle = self.lib.rth_pipeline_create(dev.handle, mesh, C.byref(s))
         if not self.handle:
             raise RuntimeError("RaytracerPipeline::Initialize failed")
@@ -174,6 +177,18 @@ class HostPipeline:
         if not self.lib.rth_pipeline_read_result(self.handle, out.ctypes.data_as(_P)):
             raise RuntimeError("ReadResult failed")
         return out
+
+    def save_state(self, path):
+        """Checkpoint of the accumulation (running-mean image + sample counter), between two sample cycles."""
+        if not self.lib.rth_pipeline_save_state(self.handle, str(path).encode()):
+            raise RuntimeError("SaveState failed")
+
+    def load_state(self, path):
+        if not self.lib.rth_pipeline_load_state(self.handle, str(path).encode()):
+            raise RuntimeError("LoadState failed")
+
+    def num_samples(self):
+        return int(self.lib.rth_pipeline_num_samples(self.handle))
 
     def read_buffer(self, which, dtype, count):
         h = self.lib.rth_pipeline_bvh(self.handle) if which == "bvh" else self.lib.rth_pipeline_morton(self.handle)

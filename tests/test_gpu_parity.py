@@ -606,3 +606,68 @@ def test_ten_million_triangle_build_properties(device, oracle):
     acc.destroy()
     for b in (idx, vtx, bvh, morton):
         b.free()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_cpp_host_dynamic_scene_matches_oracle(device, oracle, fused):
+    """Settings::DynamicScene of the C++ host: the mesh moves on the device before every sample cycle."""
+    from gpuraytracer_amd import host_py
+    from gpuraytracer_amd.capi import aabb_dtype
+    n, w, h, depth, cycles = 5000, 64, 36, 3, 3
+    sc = _scene(n)
+    hp = host_py.HostPipeline(device, n, w, h, sc["camera"], fused_build=fused, seed_raygen=1, seed_trace=2, dynamic=True)
+    op = oracle.Pipeline(sc, w, h, depth=depth, seed_raygen=1, seed_trace=2, rebuild_every_cycle=True)
+    count = oracle.load().orc_bvh_node_count(n)
+    for frame in range(cycles):
+        op.set_vertices(oracle.synthetic_animate(sc, frame)["vertices"])
+        hp.render(depth)
+        op.render(depth)
+        assert hp.read_buffer("bvh", aabb_dtype, count).tobytes() == op.bvh().tobytes(), "hierarchy differs in frame %d" % frame
+    assert hp.result().view(np.uint32).tobytes() == op.result().view(np.uint32).tobytes()
+    assert hp.num_samples() == cycles + 1
+    hp.close()
+    op.close()
+
+
+def test_checkpoint_and_resume(device, oracle, tmp_path):
+    """SaveState / LoadState of the C++ host: the running mean and the sample counter survive, and the next sample
+    is folded into the restored mean exactly as the final-image shader does (shader/CS_GenerateFinalImage.hlsl:44-53)."""
+    from gpuraytracer_amd import host_py
+    n, w, h, depth = 4000, 48, 27, 3
+    sc = _scene(n)
+    path = tmp_path / "state.bin"
+    a = host_py.HostPipeline(device, n, w, h, sc["camera"], seed_raygen=1, seed_trace=2)
+    a.render(depth)
+    with pytest.raises(RuntimeError):
+        a.render(1)
+        a.save_state(path)                    # in the middle of a sample cycle: refused
+    a.render(depth - 1)
+    a.save_state(path)
+    saved, samples = a.result(), a.num_samples()
+    assert samples == 3
+    a.close()
+
+    b = host_py.HostPipeline(device, n, w, h, sc["camera"], seed_raygen=1, seed_trace=2)
+    b.load_state(path)
+    assert b.num_samples() == samples
+    assert b.result().view(np.uint32).tobytes() == saved.view(np.uint32).tobytes()
+    b.render(depth)
+    c = host_py.HostPipeline(device, n, w, h, sc["camera"], seed_raygen=1, seed_trace=2)     # same seeds: the same first sample
+    c.render(depth)
+    new = c.result() * np.float32(2.0)        # a fresh pipeline's first mean is new / 2
+    cnt = np.float32(samples + 1)
+    inv = np.float32(1.0) / cnt
+    keep = np.float32(samples) * inv
+    want = keep * saved + inv * new
+    assert b.num_samples() == samples + 1
+    assert b.result().view(np.uint32).tobytes() == want.astype(np.float32).view(np.uint32).tobytes()
+    # a state of another image size, and a file that is no state, are refused
+    d = host_py.HostPipeline(device, n, w + 1, h, sc["camera"], seed_raygen=1, seed_trace=2)
+    with pytest.raises(RuntimeError):
+        d.load_state(path)
+    junk = tmp_path / "junk.bin"
+    junk.write_bytes(b"P6\n1 1\n255\n")
+    with pytest.raises(RuntimeError):
+        b.load_state(junk)
+    for p in (b, c, d):
+        p.close()
