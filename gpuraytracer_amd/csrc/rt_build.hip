@@ -397,14 +397,17 @@ __device__ __forceinline__ void store_node(rt_aabb* nodes, uint32_t idx, const B
 // The two triangles of a leaf, interleaved for the packed two-triangle test (80 bytes, one leaf per 128-byte line):
 //   (a0.x a1.x a0.y a1.y) (a0.z a1.z b0.x b1.x) (b0.y b1.y b0.z b1.z) (c0.x c1.x c0.y c1.y) (c0.z c1.z ci0 ci1)
 // p[0..2] = corners of triangle 0, p[3..5] of triangle 1 (a copy of triangle 0, ci1 = 0xffffffff, if there is none)
-__device__ __forceinline__ void store_leaf_triangles(float4* sorted_tris, uint32_t leaf, const float (*p)[3], uint32_t ci0,
-                                                     uint32_t ci1) {
-    float4* o = sorted_tris + RT_LEAF_STRIDE * (size_t)leaf;
+__device__ __forceinline__ void leaf_triangle_record(float4* o, const float (*p)[3], uint32_t ci0, uint32_t ci1) {
     o[0] = make_float4(p[0][0], p[3][0], p[0][1], p[3][1]);
     o[1] = make_float4(p[0][2], p[3][2], p[1][0], p[4][0]);
     o[2] = make_float4(p[1][1], p[4][1], p[1][2], p[4][2]);
     o[3] = make_float4(p[2][0], p[5][0], p[2][1], p[5][1]);
     o[4] = make_float4(p[2][2], p[5][2], __uint_as_float(ci0), __uint_as_float(ci1));
+}
+__device__ __forceinline__ void store_leaf_triangles(float4* sorted_tris, uint32_t leaf, const float (*p)[3], uint32_t ci0,
+                                                     uint32_t ci1) {
+    float4* o = sorted_tris + RT_LEAF_STRIDE * (size_t)leaf;
+    leaf_triangle_record(o, p, ci0, ci1);
     // the rest of the line is written as well: whole 128-byte lines go to memory faster than 80 bytes of each
     o[5] = o[6] = o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
@@ -541,6 +544,9 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
                                                 const float4* __restrict__ tris, float4* __restrict__ sorted_tris,
                                                 rt_aabb* __restrict__ nodes, rt_aabb* __restrict__ pairs, float4* __restrict__ quads) {
     __shared__ float s_box[256][6];
+    // the workgroup's 256 leaf records are handed over through LDS so that they leave as runs of whole lines
+    // (a lane storing its own record writes 16 bytes to each of 64 different lines per instruction: half the rate)
+    __shared__ float4 s_tri[PACKED ? 256 * 5 : 1];
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t leaves = (num_prims + 1u) / 2u;
     Box b;
@@ -572,8 +578,19 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
             b.mn[0] = fminf(b.mn[0], px); b.mn[1] = fminf(b.mn[1], py); b.mn[2] = fminf(b.mn[2], pz);
             b.mx[0] = fmaxf(b.mx[0], px); b.mx[1] = fmaxf(b.mx[1], py); b.mx[2] = fmaxf(b.mx[2], pz);
         }
-        if (PACKED) store_leaf_triangles(sorted_tris, g, corner, ci0, ci1);
+        if (PACKED) leaf_triangle_record(s_tri + 5u * threadIdx.x, corner, ci0, ci1);
         store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
+    }
+    if (PACKED) {
+        __syncthreads();
+        const uint32_t first = blockIdx.x * 256u;
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; i++) {
+            const uint32_t e = i * 256u + threadIdx.x;             // float4 e of the workgroup's 256 x 128 bytes
+            const uint32_t leaf = e >> 3, j = e & 7u;
+            if (first + leaf < leaves)
+                sorted_tris[RT_LEAF_STRIDE * (size_t)first + e] = j < 5u ? s_tri[5u * leaf + j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
     }
     if (PACKED && pairs) {                             // same for the whole grid
         const Box other = next_lane_box(b, g + 1u < leaves);

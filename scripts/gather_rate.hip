@@ -40,6 +40,22 @@ __global__ __launch_bounds__(256) void k_gather128(const float4* __restrict__ t,
 
 // What a 16-byte load costs when the four lanes of a quad read 64 contiguous bytes of one record (each quad its
 // own random record) against every lane reading 16 bytes of its own record: the address/tag rate of the L1 path.
+// ... and when all 64 lanes of a wave (SHARE = 6), or groups of 2^SHARE neighbouring lanes, read the very same 16 bytes
+template <int SHARE>
+__global__ __launch_bounds__(256) void k_same(const float4* __restrict__ t, uint32_t records, uint32_t per_lane, float* out) {
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    uint32_t s = (id >> SHARE) * 2654435761u + 12345u;
+    float acc = 0.0f;
+    for (uint32_t j = 0; j < per_lane; j++) {
+        s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+        const float4* r = t + 4 * (size_t)(s & (records - 1u));
+        float4 a = r[0];
+        acc += a.x;
+        s += __float_as_uint(acc) & 1u;
+    }
+    if (acc == 1.2345f) out[0] = acc;
+}
+
 template <bool QUAD>
 __global__ __launch_bounds__(256) void k_access(const float4* __restrict__ t, uint32_t records, uint32_t per_lane, float* out) {
     const uint32_t id = blockIdx.x * 256u + threadIdx.x;
@@ -109,6 +125,21 @@ int main() {
                    quad ? "four lanes on one record's 64 bytes" : "every lane on its own record     ", ms, n / ms / 1e6,
                    n / ms / 1e6 / 256 / 2.4);
         }
+    for (int share : {1, 2, 4, 6}) {
+        const uint32_t records = (16u << 10) / 64, per_lane = 1024, blocks = 256u * 3u;
+        float ms = 0.0f;
+        for (int rep = 0; rep < 2; rep++) {
+            hipEventRecord(a);
+            if (share == 1) hipLaunchKernelGGL(k_same<1>, dim3(blocks), dim3(256), 0, 0, t, records, per_lane, out);
+            if (share == 2) hipLaunchKernelGGL(k_same<2>, dim3(blocks), dim3(256), 0, 0, t, records, per_lane, out);
+            if (share == 4) hipLaunchKernelGGL(k_same<4>, dim3(blocks), dim3(256), 0, 0, t, records, per_lane, out);
+            if (share == 6) hipLaunchKernelGGL(k_same<6>, dim3(blocks), dim3(256), 0, 0, t, records, per_lane, out);
+            hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+        }
+        const double n = (double)blocks * 256 * per_lane;
+        printf("table      16 KiB  16-byte loads, %2d neighbouring lanes on the same address: %7.3f ms  %6.1f G loads/s  %.2f per clock and CU\n",
+               1 << share, ms, n / ms / 1e6, n / ms / 1e6 / 256 / 2.4);
+    }
     for (size_t sz : {(size_t)1 << 20, (size_t)64 << 20, big})
         for (int bpc : {2, 4}) {
             const uint32_t records = (uint32_t)(sz / 128), per_lane = 1024, blocks = 256u * bpc;
