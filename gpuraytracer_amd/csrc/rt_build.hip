@@ -432,37 +432,58 @@ __device__ __forceinline__ void store_pair_half(rt_aabb* pairs, uint32_t pair_sl
     p[6 + child] = a.mx[0]; p[8 + child] = a.mx[1]; p[10 + child] = a.mx[2];
     p[12 + 2u * child] = __uint_as_float(a0); p[13 + 2u * child] = __uint_as_float(a1);
 }
-// The four-grandchildren records (rt_quad_records) are written along with the pair records: the pair record of the
-// children of node c (index ci of level k + 1) is one half of the 128-byte record of c's parent, which exists where
-// level k + 2 does and k is even. The last node of a level with an odd count has no sibling: its parent's second
-// half is NaNs.
-__device__ __forceinline__ float4* quad_half(float4* quads, const rt_levels& lv, uint32_t k, uint32_t ci) {
+// The four-grandchildren records (rt_quad_records) are written along with the pair records: the pair of the children
+// of node c (index ci of level k + 1) is one half of the 64-byte record of c's parent, which exists where level k + 2
+// does and k is even. A record holds boxes that CONTAIN the true ones, in binary16: every minimum rounded down, every
+// maximum rounded up. Half p of record h is six dwords at dword 6p, one per component (min x y z, max x y z), each a
+// pair (first node, second node) of binary16 values; dwords 12 - 15 are padding. The last node of a level with an odd
+// count has no sibling: its parent's second half is NaNs.
+__device__ __forceinline__ uint32_t half_bits_below(float x) {      // the largest binary16 value <= x
+    _Float16 hf = (_Float16)x;                                      // round to nearest
+    uint32_t b = (uint32_t)__builtin_bit_cast(unsigned short, hf);
+    if ((float)hf > x) b = (b == 0u) ? 0x8001u : ((b & 0x8000u) ? b + 1u : b - 1u);      // one step towards -infinity
+    return b;                                                       // NaN stays NaN; beyond the range: -inf or 65504
+}
+__device__ __forceinline__ uint32_t half_bits_above(float x) { return half_bits_below(-x) ^ 0x8000u; }
+__device__ __forceinline__ void quad_half_dwords(const Box& a, const Box& b, uint32_t* d) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        d[c] = half_bits_below(a.mn[c]) | (half_bits_below(b.mn[c]) << 16);
+        d[3 + c] = half_bits_above(a.mx[c]) | (half_bits_above(b.mx[c]) << 16);
+    }
+}
+__device__ __forceinline__ uint32_t* quad_half(float4* quads, const rt_levels& lv, uint32_t k, uint32_t ci) {
     const uint32_t c = lv.aoff[k + 1u] + ci;                   // slot of node c
-    return quads + 8 * (size_t)(c >> 1) + 3u * (c & 1u);
+    return reinterpret_cast<uint32_t*>(quads + RT_QUAD_STRIDE * (size_t)(c >> 1)) + 6u * (c & 1u);
 }
 __device__ __forceinline__ bool quad_level(const rt_levels& lv, uint32_t k) { return !(k & 1u) && k + 2u < lv.count; }
 __device__ __forceinline__ void store_quad_pair(float4* quads, const rt_levels& lv, uint32_t k, uint32_t ci, const Box& a,
                                                 const Box& b) {
-    float4* o = quad_half(quads, lv, k, ci);
-    o[0] = make_float4(a.mn[0], b.mn[0], a.mn[1], b.mn[1]);
-    o[1] = make_float4(a.mn[2], b.mn[2], a.mx[0], b.mx[0]);
-    o[2] = make_float4(a.mx[1], b.mx[1], a.mx[2], b.mx[2]);
-    if (!(ci & 1u) && ci + 1u >= lv.n[k + 1u]) {
-        const float nan = __uint_as_float(0x7fc00000u);
-        o[3] = o[4] = o[5] = make_float4(nan, nan, nan, nan);
+    uint32_t* o = quad_half(quads, lv, k, ci);
+    uint32_t d[6];
+    quad_half_dwords(a, b, d);
+    uint2* o2 = reinterpret_cast<uint2*>(o);                   // halves start at multiples of 8 bytes
+    o2[0] = make_uint2(d[0], d[1]); o2[1] = make_uint2(d[2], d[3]); o2[2] = make_uint2(d[4], d[5]);
+    if (ci & 1u) {
+        o2[3] = make_uint2(0u, 0u); o2[4] = make_uint2(0u, 0u);                 // padding
+    } else if (ci + 1u >= lv.n[k + 1u]) {
+        const uint2 nan = make_uint2(0x7e007e00u, 0x7e007e00u);
+        o2[3] = nan; o2[4] = nan; o2[5] = nan;
+        o2[6] = make_uint2(0u, 0u); o2[7] = make_uint2(0u, 0u);
     }
 }
-// one node's half of its pair (where the sibling is produced by another workgroup); child = 0 or 1
+// one node's part of its pair (where the sibling is produced by another workgroup); child = 0 or 1
 __device__ __forceinline__ void store_quad_pair_half(float4* quads, const rt_levels& lv, uint32_t k, uint32_t ci, uint32_t child,
                                                      const Box& a) {
-    float4* o = quad_half(quads, lv, k, ci);
-    float* p = reinterpret_cast<float*>(o);
-    p[0 + child] = a.mn[0]; p[2 + child] = a.mn[1]; p[4 + child] = a.mn[2];
-    p[6 + child] = a.mx[0]; p[8 + child] = a.mx[1]; p[10 + child] = a.mx[2];
-    if (child == 0u && !(ci & 1u) && ci + 1u >= lv.n[k + 1u]) {
-        const float nan = __uint_as_float(0x7fc00000u);
-        o[3] = o[4] = o[5] = make_float4(nan, nan, nan, nan);
+    uint32_t* o = quad_half(quads, lv, k, ci);
+    unsigned short* p = reinterpret_cast<unsigned short*>(o) + child;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        p[2 * c] = (unsigned short)half_bits_below(a.mn[c]);
+        p[2 * (3 + c)] = (unsigned short)half_bits_above(a.mx[c]);
     }
+    if (child == 0u && !(ci & 1u) && ci + 1u >= lv.n[k + 1u])
+        for (int c = 0; c < 6; c++) o[6 + c] = 0x7e007e00u;
 }
 
 // the next lane's box, or - where the next node does not exist - a box of NaNs, which no box built from
@@ -662,9 +683,15 @@ __global__ __launch_bounds__(256) void k_pairs_from_nodes(rt_levels lv, uint32_t
     store_pair(pairs, lv.aoff[k] + i, ba, bb, __float_as_uint(ahi.z), __float_as_uint(ahi.w), b0, b1);
 }
 
-// The four-grandchildren records (rt_quad_records) from the pair records: the record of slot h is the pair records
-// of its children 2h and 2h + 1 one after the other. One thread per slot below 2^(root level - 1); slots an odd number
-// of levels above the leaves, and slots of nodes that do not exist, have no record.
+// The four-grandchildren records (rt_quad_records) from the pair records: the record of slot h holds the pair records
+// of its children 2h and 2h + 1, widened to binary16 (see store_quad_pair). One thread per slot below
+// 2^(root level - 1); slots an odd number of levels above the leaves, and slots of nodes that do not exist, have no record.
+__device__ __forceinline__ void pair_record_boxes(const float4* r, Box& a, Box& b) {
+    const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+    a.mn[0] = q0.x; b.mn[0] = q0.y; a.mn[1] = q0.z; b.mn[1] = q0.w;
+    a.mn[2] = q1.x; b.mn[2] = q1.y; a.mx[0] = q1.z; b.mx[0] = q1.w;
+    a.mx[1] = q2.x; b.mx[1] = q2.y; a.mx[2] = q2.z; b.mx[2] = q2.w;
+}
 __global__ __launch_bounds__(256) void k_quads_from_pairs(rt_levels lv, uint32_t slots, const float4* __restrict__ pairs,
                                                           float4* __restrict__ quads) {
     const uint32_t h = blockIdx.x * 256u + threadIdx.x;
@@ -675,15 +702,19 @@ __global__ __launch_bounds__(256) void k_quads_from_pairs(rt_levels lv, uint32_t
     if ((k & 1u) || k < 2u) return;
     const uint32_t i = h - (1u << depth);
     if (i >= lv.n[k]) return;
-    const float4* a = pairs + 4 * (size_t)(2u * h);
-    float4* o = quads + 8 * (size_t)h;
-    o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
+    uint32_t d[16];
+    Box a, b;
+    pair_record_boxes(pairs + 4 * (size_t)(2u * h), a, b);
+    quad_half_dwords(a, b, d);
     if (2u * i + 1u < lv.n[k - 1u]) {
-        o[3] = a[4]; o[4] = a[5]; o[5] = a[6];
+        pair_record_boxes(pairs + 4 * (size_t)(2u * h + 1u), a, b);
+        quad_half_dwords(a, b, d + 6);
     } else {
-        const float nan = __uint_as_float(0x7fc00000u);
-        o[3] = o[4] = o[5] = make_float4(nan, nan, nan, nan);
+        for (int c = 0; c < 6; c++) d[6 + c] = 0x7e007e00u;
     }
+    d[12] = d[13] = d[14] = d[15] = 0u;
+    uint4* o = reinterpret_cast<uint4*>(quads + RT_QUAD_STRIDE * (size_t)h);
+    for (int c = 0; c < 4; c++) o[c] = make_uint4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]);
 }
 
 // ... and the Morton-ordered packed triangles from the leaves' links
@@ -889,7 +920,7 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
         rt_make_levels(max_primitives, &lv);
         // a smaller scene packed later never needs more slots than the largest one
         if (e == hipSuccess) e = hipMalloc((void**)&a->pairs, (rt_aligned_node_slots(&lv) + 64u) * sizeof(rt_aabb));
-        if (e == hipSuccess) e = hipMalloc((void**)&a->quads, rt_quad_records(&lv) * 128u);
+        if (e == hipSuccess) e = hipMalloc((void**)&a->quads, rt_quad_records(&lv) * RT_QUAD_STRIDE * sizeof(float4));
     }
     if (e != hipSuccess) {
         rt_accel_destroy(a);

@@ -54,7 +54,7 @@ struct rt_accel {
     uint32_t num_prims;        // set by rt_accel_pack
     float4* tris;              // [3*max_prims] packed positions, original order
     float4* sorted_tris;       // [RT_LEAF_STRIDE * leaves] the two triangles of every leaf in Morton order, interleaved
-    float4* quads;             // second private copy of the hierarchy, four grandchildren per 128-byte record (see rt_quad_records)
+    float4* quads;             // second private copy of the hierarchy, four grandchildren per 64-byte record (see rt_quad_records)
     rt_aabb* pairs;            // private copy of the hierarchy as interleaved sibling pairs (rt_levels::aoff placement)
     uint2* keys_a;             // [max_prims] (code, 3*tri)
     uint2* keys_b;             // [max_prims]
@@ -134,11 +134,14 @@ static inline bool rt_make_levels(uint32_t num_prims, rt_levels* lv) {
 // per line touched, not per byte (measured: random 128-byte records are fetched at the rate of 64-byte ones),
 // and an 80-byte stride makes every second leaf straddle two lines.
 #define RT_LEAF_STRIDE 8u      // in float4
-// The traversal's second copy: the node in slot h has a 128-byte record at quads[8h] with the boxes of its four
-// grandchildren (slots 4h .. 4h + 3) - the pair records of its children 2h and 2h + 1, 48 bytes each, one after the
-// other - so that one line read takes the walk two levels down. Only nodes an even number of levels above the
-// leaves have records (slots of the other depths are left unused); grandchildren that do not exist are NaNs.
-// number of 128-byte records: one per slot below 2^(root level - 1)
+// The traversal's second copy: the node in slot h has a 64-byte record at quads[RT_QUAD_STRIDE * h] with boxes of its
+// four grandchildren (slots 4h .. 4h + 3), so that one read takes the walk two levels down. The boxes are in binary16
+// and CONTAIN the true ones (minima rounded down, maxima rounded up): the walk may enter a node the reference would
+// not, never the other way round, and every leaf it reaches is tested against its exact box again (recomputed from
+// the leaf's triangles) before its triangles are. Only nodes an even number of levels above the leaves have records
+// (slots of the other depths are left unused); grandchildren that do not exist are NaNs.
+#define RT_QUAD_STRIDE 4u      // in float4
+// number of records: one per slot below 2^(root level - 1)
 static inline size_t rt_quad_records(const rt_levels* lv) { return lv->count >= 3u ? (size_t)1u << (lv->count - 2u) : 1u; }
 // 32-byte slots the private copy needs
 static inline size_t rt_aligned_node_slots(const rt_levels* lv) { return (size_t)2u << (lv->count - 1u); }

@@ -620,22 +620,56 @@ static_assert(kFifo <= 15u, "the waiting count shares w with the state flags");
 
 // ---- two levels per step: the walk on the four-grandchildren records ----
 //
-// Past the L2 the memory system delivers random reads at a fixed rate of 128-byte lines, whatever part of the
-// line is used, and that rate bounds the walk. One step of this kernel reads the one line that holds the boxes
-// of the entered node's four grandchildren (slots 4h .. 4h + 3) and tests all four, instead of one 64-byte record
-// for the two children and one more for every child that is hit.
-// Why the result stays the reference's: a grandchild's box lies inside its parent's, every operation of the slab
-// test is monotone, so a grandchild that passes (entry distance below the closest hit) has a parent that passes;
-// testing the grandchildren of a child that fails finds nothing. Boxes are tested earlier than in the reference's
-// walk, i.e. against a closest hit that can only be larger, which adds visits but no result: every leaf still goes
-// through the in-order list and its delayed comparison (see k_traverse).
-// A box is entered if !(tfar < max(tnear, lim)) && tnear != 1e30 && tnear < closest, with lim = tmin if tmin > 0, else
-// the smallest positive float: "tfar <= 0 || tfar < tmin" of the reference's slab test (shader/CS_TraceRays.hlsl:81-97)
-// is "tfar < lim" for every float, and its "tnear > tmax" never holds where tnear < closest <= tmax does. A missing
-// node (a box of NaNs) fails "tnear < closest". Byte offsets into the record and leaf arrays are 32-bit: the launcher
-// uses this kernel only below 4 GiB each.
+// Past the L2 the memory system delivers random reads at a fixed rate of 128-byte lines, whatever part of the line is
+// used, and in front of it the L1 path takes about 1.4 lane-loads of 16 bytes per clock and CU; both bound the walk.
+// One step of this kernel reads the 64-byte record that holds boxes of the entered node's four grandchildren (slots
+// 4h .. 4h + 3; three loads per lane) and tests all four, instead of one 64-byte record for the two children and one
+// more for every child that is hit.
+//
+// The boxes of those records are binary16 boxes that CONTAIN the true ones, and that is enough:
+//  * every operation of the slab test is monotone, so a ray that passes a true box (entry distance below the closest
+//    hit) passes every box that contains it - in particular the widened boxes of the node and of all its ancestors.
+//    The walk therefore reaches every leaf the reference's walk reaches, in the same left-first order, plus some it
+//    does not. (A direction component of exactly zero gives the reference's test 0 * inf = NaN on a box plane through
+//    the origin; the widened test uses a huge finite reciprocal for such a component, which keeps it monotone.)
+//  * a leaf that is reached goes into the lane's in-order list with its (widened) entry distance. When its turn comes,
+//    the leaf's exact box is recomputed from its triangles - the build takes that box as the minimum and maximum of
+//    the same six corners - and tested exactly as the reference tests it, against the closest hit of that moment.
+//    If it passes, every ancestor's exact box passed in the reference's walk (it contains the leaf's box, and the
+//    closest hit was no smaller then), so the reference visits this leaf, at this point of its order; if it fails,
+//    the reference does not test its triangles either. The triangles tested, their order and the closest hit they
+//    are compared with are the reference's; the box tests in between only decide how much extra work is done.
 // Noted nodes: one nibble per step taken down; bit j of the lowest nibble = slot (h & ~3) | j waits, in order.
-// A hierarchy with an odd number of levels below the trunk starts with the trunk's two children (pair record 1).
+// A hierarchy with an odd number of levels below the trunk starts with the trunk's two children (pair record 1, exact).
+// lim = tmin if tmin > 0, else the smallest positive float: "tfar <= 0 || tfar < tmin" of the reference's slab test
+// (shader/CS_TraceRays.hlsl:81-97) is "tfar < lim" for every float, and its "tnear > tmax" never holds where
+// tnear < closest <= tmax does. Byte offsets into the record and leaf arrays are 32-bit: the launcher uses this
+// kernel only below 4 GiB each.
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f half_pair(uint32_t d) {
+    const v2h h = __builtin_bit_cast(v2h, d);
+    return v2f{(float)h.x, (float)h.y};
+}
+
+// exact box of a leaf (minimum / maximum of its six corners, from +-1e30 as shader/CS_BVHBuildLeaves.hlsl:31-52 has
+// it) and the reference's test of it; true if the leaf's triangles are to be tested
+__device__ __forceinline__ bool leaf_box_passes(f3 o, f3 inv_d, float lim, float closest, float4 l0, float4 l1, float4 l2, float4 l3,
+                                                float4 l4) {
+    const float big = 1e30f, small = -1e30f;
+    const float mnx = vmin3(vmin3(l0.x, l0.y, l1.z), vmin3(l1.w, l3.x, l3.y), big);
+    const float mny = vmin3(vmin3(l0.z, l0.w, l2.x), vmin3(l2.y, l3.z, l3.w), big);
+    const float mnz = vmin3(vmin3(l1.x, l1.y, l2.z), vmin3(l2.w, l4.x, l4.y), big);
+    const float mxx = vmax3(vmax3(l0.x, l0.y, l1.z), vmax3(l1.w, l3.x, l3.y), small);
+    const float mxy = vmax3(vmax3(l0.z, l0.w, l2.x), vmax3(l2.y, l3.z, l3.w), small);
+    const float mxz = vmax3(vmax3(l1.x, l1.y, l2.z), vmax3(l2.w, l4.x, l4.y), small);
+    const v2f tx = (v2f{mnx, mxx} - v2f{o.x, o.x}) * v2f{inv_d.x, inv_d.x};
+    const v2f ty = (v2f{mny, mxy} - v2f{o.y, o.y}) * v2f{inv_d.y, inv_d.y};
+    const v2f tz = (v2f{mnz, mxz} - v2f{o.z, o.z}) * v2f{inv_d.z, inv_d.z};
+    const float tn = vmax3(vmin(tx.x, tx.y), vmin(ty.x, ty.y), vmin(tz.x, tz.y));
+    const float tf = vmin3(vmax(tx.x, tx.y), vmax(ty.x, ty.y), vmax(tz.x, tz.y));
+    return !(tf < vmax(tn, lim)) && (tn != 1e30f) && (tn < closest);
+}
+
 __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const float4* __restrict__ rays, const float4* __restrict__ nodes,
                                                        const float4* __restrict__ pairs, const float4* __restrict__ quads,
                                                        const float4* __restrict__ sorted_tris, float4* __restrict__ hit_records,
@@ -655,6 +689,7 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
     uint32_t ray = 0u;                // index of the ray this lane is walking (while w < kIdle)
     uint32_t w = kIdle;
     f3 org = mk(0.0f, 0.0f, 0.0f), dir = org, inv_d = org;
+    f3 inv_w = org;                   // reciprocals used with the widened boxes: finite where the direction is zero
     float tmin_r = 0.0f, tmax_r = 0.0f, lim = 0.0f;
     Hit best;
     best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
@@ -695,6 +730,8 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
                             tmin_r = r1.z; tmax_r = r1.w;
                             lim = (tmin_r > 0.0f) ? tmin_r : __uint_as_float(1u);
                             inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                            inv_w = mk(dir.x == 0.0f ? copysignf(3.0e38f, inv_d.x) : inv_d.x, dir.y == 0.0f ? copysignf(3.0e38f, inv_d.y) : inv_d.y,
+                                       dir.z == 0.0f ? copysignf(3.0e38f, inv_d.z) : inv_d.z);
                             best.t = tmax_r; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
                             best_ci = 0u;
                             // the trunk is entered on any box hit
@@ -729,14 +766,15 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
         unsigned long long waiting_mask, walking_mask;
         for (;;) {
             if (w <= kFifo - 4u) {
-                const float4* rec = reinterpret_cast<const float4*>(quad_bytes + (h << 7));
-                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5];
+                const uint4* rec = reinterpret_cast<const uint4*>(quad_bytes + (h << 6));
+                const uint4 u0 = rec[0], u1 = rec[1], u2 = rec[2];
                 const v2f ox = {org.x, org.x}, oy = {org.y, org.y}, oz = {org.z, org.z};
-                const v2f ix = {inv_d.x, inv_d.x}, iy = {inv_d.y, inv_d.y}, iz = {inv_d.z, inv_d.z};
-                const v2f ax = (v2f{q0.x, q0.y} - ox) * ix, ay = (v2f{q0.z, q0.w} - oy) * iy, az = (v2f{q1.x, q1.y} - oz) * iz;
-                const v2f bx = (v2f{q1.z, q1.w} - ox) * ix, by = (v2f{q2.x, q2.y} - oy) * iy, bz = (v2f{q2.z, q2.w} - oz) * iz;
-                const v2f cx = (v2f{q3.x, q3.y} - ox) * ix, cy = (v2f{q3.z, q3.w} - oy) * iy, cz = (v2f{q4.x, q4.y} - oz) * iz;
-                const v2f dx = (v2f{q4.z, q4.w} - ox) * ix, dy = (v2f{q5.x, q5.y} - oy) * iy, dz = (v2f{q5.z, q5.w} - oz) * iz;
+                const v2f ix = {inv_w.x, inv_w.x}, iy = {inv_w.y, inv_w.y}, iz = {inv_w.z, inv_w.z};
+                // first pair (slots 4h, 4h + 1): dwords 0 - 5 = min x y z, max x y z; second pair: dwords 6 - 11
+                const v2f ax = (half_pair(u0.x) - ox) * ix, ay = (half_pair(u0.y) - oy) * iy, az = (half_pair(u0.z) - oz) * iz;
+                const v2f bx = (half_pair(u0.w) - ox) * ix, by = (half_pair(u1.x) - oy) * iy, bz = (half_pair(u1.y) - oz) * iz;
+                const v2f cx = (half_pair(u1.z) - ox) * ix, cy = (half_pair(u1.w) - oy) * iy, cz = (half_pair(u2.x) - oz) * iz;
+                const v2f dx = (half_pair(u2.y) - ox) * ix, dy = (half_pair(u2.z) - oy) * iy, dz = (half_pair(u2.w) - oz) * iz;
                 const float tn0 = vmax3(vmin(ax.x, bx.x), vmin(ay.x, by.x), vmin(az.x, bz.x));
                 const float tn1 = vmax3(vmin(ax.y, bx.y), vmin(ay.y, by.y), vmin(az.y, bz.y));
                 const float tn2 = vmax3(vmin(cx.x, dx.x), vmin(cy.x, dy.x), vmin(cz.x, dz.x));
@@ -745,10 +783,10 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
                 const float tx1 = vmin3(vmax(ax.y, bx.y), vmax(ay.y, by.y), vmax(az.y, bz.y));
                 const float tx2 = vmin3(vmax(cx.x, dx.x), vmax(cy.x, dy.x), vmax(cz.x, dz.x));
                 const float tx3 = vmin3(vmax(cx.y, dx.y), vmax(cy.y, dy.y), vmax(cz.y, dz.y));
-                const bool hit0 = !(tx0 < vmax(tn0, lim)) && (tn0 != 1e30f) && (tn0 < best.t);
-                const bool hit1 = !(tx1 < vmax(tn1, lim)) && (tn1 != 1e30f) && (tn1 < best.t);
-                const bool hit2 = !(tx2 < vmax(tn2, lim)) && (tn2 != 1e30f) && (tn2 < best.t);
-                const bool hit3 = !(tx3 < vmax(tn3, lim)) && (tn3 != 1e30f) && (tn3 < best.t);
+                const bool hit0 = !(tx0 < vmax(tn0, lim)) && (tn0 < best.t);
+                const bool hit1 = !(tx1 < vmax(tn1, lim)) && (tn1 < best.t);
+                const bool hit2 = !(tx2 < vmax(tn2, lim)) && (tn2 < best.t);
+                const bool hit3 = !(tx3 < vmax(tn3, lim)) && (tn3 < best.t);
                 const uint32_t m = (hit0 ? 1u : 0u) | (hit1 ? 2u : 0u) | (hit2 ? 4u : 0u) | (hit3 ? 8u : 0u);
                 if (h < first_leaf_grandparent && m != 0u) {
                     trail = (trail << 4) | (unsigned long long)(m & (m - 1u));
@@ -789,11 +827,13 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
                 if (__uint_as_float(e.y) < best.t) {
                     const float4* t = reinterpret_cast<const float4*>(leaf_bytes + e.x * 128u);
                     const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
-                    const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
-                    Hit h0, h1;
-                    intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
-                    check_hit(h0, tmin_r, tmax_r, ci0, best, best_ci);
-                    if (ci1 != 0xffffffffu) check_hit(h1, tmin_r, tmax_r, ci1, best, best_ci);
+                    if (leaf_box_passes(org, inv_d, lim, best.t, l0, l1, l2, l3, l4)) {
+                        const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
+                        Hit h0, h1;
+                        intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
+                        check_hit(h0, tmin_r, tmax_r, ci0, best, best_ci);
+                        if (ci1 != 0xffffffffu) check_hit(h1, tmin_r, tmax_r, ci1, best, best_ci);
+                    }
                 }
             }
         }
@@ -896,7 +936,7 @@ int convert_workspace(rt_device* dev, uint32_t num_prims, const rt_levels& lv) {
     // both sizes grow with the primitive count
     hipError_t e = hipMalloc((void**)&dev->conv_pairs, rt_aligned_node_slots(&lv) * sizeof(rt_aabb));
     if (e == hipSuccess) e = hipMalloc((void**)&dev->conv_tris, (size_t)lv.n[0] * RT_LEAF_STRIDE * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc((void**)&dev->conv_quads, rt_quad_records(&lv) * 128u);
+    if (e == hipSuccess) e = hipMalloc((void**)&dev->conv_quads, rt_quad_records(&lv) * RT_QUAD_STRIDE * sizeof(float4));
     if (e != hipSuccess) return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
     dev->conv_capacity = num_prims;
     return RT_OK;
