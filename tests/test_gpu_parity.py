@@ -671,3 +671,24 @@ def test_checkpoint_and_resume(device, oracle, tmp_path):
         b.load_state(junk)
     for p in (b, c, d):
         p.close()
+
+
+@pytest.mark.parametrize("scale,offset", [(0.05, 0.0), (3000.0, 7000.0), (1e5, -2e5), (1.0, 65000.0)])
+def test_widened_boxes_stay_exact_at_extreme_coordinates(device, oracle, scale, offset):
+    """The two-level kernel walks on binary16 boxes that contain the true ones. Coordinates that binary16 holds badly
+    (denormal, coarse, or beyond its range, where the boxes become infinite) may cost time, never a different image."""
+    sc = dict(_small_scene(300, seed=11))
+    v = sc["vertices"].copy()
+    v["position"] = (v["position"].astype(np.float64) * scale + offset).astype(np.float32)
+    sc["vertices"] = v
+    from gpuraytracer_amd import scenes
+    sc["scene_min"], sc["scene_max"] = scenes.centroid_bounds(v, sc["indices"])
+    cam = dict(sc["camera"])
+    cam["position"] = tuple(np.float32(c * scale + offset) for c in (0.0, 0.0, -3.0))
+    cam["focus"] = tuple(np.float32(offset) for _ in range(3))
+    cam["near_z"], cam["far_z"] = 0.01 * scale, 10000.0 * scale
+    sc["camera"] = cam
+    g = _render_both(device, oracle, sc, 64, 48, 4, depth=2)
+    for name, a, b in (("tone-mapped", g[0], g[1]), ("result", g[2], g[3]), ("emitted", g[4], g[5]), ("rays", g[6], g[7])):
+        assert a.view(np.uint32).tobytes() == b.view(np.uint32).tobytes(), "%s differs at scale %g" % (name, scale)
+    assert g[8]["rays_hit"] > 0, "some ray must hit"
