@@ -34,12 +34,12 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak
 BUILD_BYTES_PER_TRIANGLE = 252  # Morton 56 + sort 80 + leaves 68 + upper levels 48 (reference data layout)
 
 # HBM-side bytes of ONE k_traverse_quad launch of the default workload on one GPU, from the hardware-counter passes
-# committed as profiles/r1_c3_quad_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in runs of their
+# committed as profiles/r1_c3_final_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in runs of their
 # own, kilobytes -> bytes): the kernel's reads past L2 are gathers of 64-byte requests, for which FETCH_SIZE counts
 # the bytes exactly (scripts/calib_fetch.hip; the doubling the microarchitecture guide prescribes applies to wide
 # streaming reads, which this kernel does not issue). Counters cannot be read inside a timed run, so the figure is
 # carried here and reported only for the configuration it was measured on.
-MEASURED_TRAFFIC = {("c3", 1): {"fetch": 215262213.5e3, "write": 702763.0e3}}
+MEASURED_TRAFFIC = {("c3", 1): {"fetch": 161478312.1e3, "write": 491278.1e3}}
 
 WORKLOADS = {
     # name: (triangles, width, height, rays/pixel, bounces, description)
@@ -221,7 +221,7 @@ def main():
         "roofline": {"kernel": "k_traverse_quad", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4),
                      "traffic": int(traffic["fetch"] + traffic["write"]) if traffic else None,
-                     "traffic_source": "profiles/r1_c3_quad_pmc_summary.txt (FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
+                     "traffic_source": "profiles/r1_c3_final_pmc_summary.txt (FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
                      "note": "algorithmic bytes are those of the reference's data layout (32 B per box test, 48 B per triangle "
                              "test); most of them are served by L1/L2, so achieved may exceed the HBM peak - "
                              "traffic is what actually crossed the memory side",
