@@ -442,6 +442,9 @@ __device__ __forceinline__ uint32_t half_bits_below(float x) {      // the large
     _Float16 hf = (_Float16)x;                                      // round to nearest
     uint32_t b = (uint32_t)__builtin_bit_cast(unsigned short, hf);
     if ((float)hf > x) b = (b == 0u) ? 0x8001u : ((b & 0x8000u) ? b + 1u : b - 1u);      // one step towards -infinity
+    // no denormals in the records (whatever an instruction does with them, the boxes stay valid): down to the next
+    // normal value or to zero
+    if (!(b & 0x7c00u) && (b & 0x03ffu)) b = (b & 0x8000u) ? 0x8400u : 0x0000u;
     return b;                                                       // NaN stays NaN; beyond the range: -inf or 65504
 }
 __device__ __forceinline__ uint32_t half_bits_above(float x) { return half_bits_below(-x) ^ 0x8000u; }

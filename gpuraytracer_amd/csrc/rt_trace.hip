@@ -645,10 +645,13 @@ static_assert(kFifo <= 15u, "the waiting count shares w with the state flags");
 // (shader/CS_TraceRays.hlsl:81-97) is "tfar < lim" for every float, and its "tnear > tmax" never holds where
 // tnear < closest <= tmax does. Byte offsets into the record and leaf arrays are 32-bit: the launcher uses this
 // kernel only below 4 GiB each.
-typedef _Float16 v2h __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f half_pair(uint32_t d) {
-    const v2h h = __builtin_bit_cast(v2h, d);
-    return v2f{(float)h.x, (float)h.y};
+// (binary16 pair d) - o for both halves: v_fma_mix_f32 converts its binary16 operand on the way in, and b * 1.0 - o
+// rounds once, exactly as the subtraction b - o does
+__device__ __forceinline__ v2f half_pair_minus(uint32_t d, float o) {
+    float lo, hi;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(d), "v"(o));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(d), "v"(o));
+    return v2f{lo, hi};
 }
 
 // exact box of a leaf (minimum / maximum of its six corners, from +-1e30 as shader/CS_BVHBuildLeaves.hlsl:31-52 has
@@ -690,6 +693,7 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
     uint32_t w = kIdle;
     f3 org = mk(0.0f, 0.0f, 0.0f), dir = org, inv_d = org;
     f3 inv_w = org;                   // reciprocals used with the widened boxes: finite where the direction is zero
+    bool neg_x = false, neg_y = false, neg_z = false;      // the ray travels downwards on that axis
     float tmin_r = 0.0f, tmax_r = 0.0f, lim = 0.0f;
     Hit best;
     best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
@@ -732,6 +736,7 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
                             inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
                             inv_w = mk(dir.x == 0.0f ? copysignf(3.0e38f, inv_d.x) : inv_d.x, dir.y == 0.0f ? copysignf(3.0e38f, inv_d.y) : inv_d.y,
                                        dir.z == 0.0f ? copysignf(3.0e38f, inv_d.z) : inv_d.z);
+                            neg_x = inv_w.x < 0.0f; neg_y = inv_w.y < 0.0f; neg_z = inv_w.z < 0.0f;
                             best.t = tmax_r; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
                             best_ci = 0u;
                             // the trunk is entered on any box hit
@@ -768,21 +773,19 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
             if (w <= kFifo - 4u) {
                 const uint4* rec = reinterpret_cast<const uint4*>(quad_bytes + (h << 6));
                 const uint4 u0 = rec[0], u1 = rec[1], u2 = rec[2];
-                const v2f ox = {org.x, org.x}, oy = {org.y, org.y}, oz = {org.z, org.z};
                 const v2f ix = {inv_w.x, inv_w.x}, iy = {inv_w.y, inv_w.y}, iz = {inv_w.z, inv_w.z};
-                // first pair (slots 4h, 4h + 1): dwords 0 - 5 = min x y z, max x y z; second pair: dwords 6 - 11
-                const v2f ax = (half_pair(u0.x) - ox) * ix, ay = (half_pair(u0.y) - oy) * iy, az = (half_pair(u0.z) - oz) * iz;
-                const v2f bx = (half_pair(u0.w) - ox) * ix, by = (half_pair(u1.x) - oy) * iy, bz = (half_pair(u1.y) - oz) * iz;
-                const v2f cx = (half_pair(u1.z) - ox) * ix, cy = (half_pair(u1.w) - oy) * iy, cz = (half_pair(u2.x) - oz) * iz;
-                const v2f dx = (half_pair(u2.y) - ox) * ix, dy = (half_pair(u2.z) - oy) * iy, dz = (half_pair(u2.w) - oz) * iz;
-                const float tn0 = vmax3(vmin(ax.x, bx.x), vmin(ay.x, by.x), vmin(az.x, bz.x));
-                const float tn1 = vmax3(vmin(ax.y, bx.y), vmin(ay.y, by.y), vmin(az.y, bz.y));
-                const float tn2 = vmax3(vmin(cx.x, dx.x), vmin(cy.x, dy.x), vmin(cz.x, dz.x));
-                const float tn3 = vmax3(vmin(cx.y, dx.y), vmin(cy.y, dy.y), vmin(cz.y, dz.y));
-                const float tx0 = vmin3(vmax(ax.x, bx.x), vmax(ay.x, by.x), vmax(az.x, bz.x));
-                const float tx1 = vmin3(vmax(ax.y, bx.y), vmax(ay.y, by.y), vmax(az.y, bz.y));
-                const float tx2 = vmin3(vmax(cx.x, dx.x), vmax(cy.x, dy.x), vmax(cz.x, dz.x));
-                const float tx3 = vmin3(vmax(cx.y, dx.y), vmax(cy.y, dy.y), vmax(cz.y, dz.y));
+                // first pair (slots 4h, 4h + 1): dwords 0 - 5 = min x y z, max x y z; second pair: dwords 6 - 11.
+                // The plane a ray meets first on an axis is the minimum if it travels upwards, else the maximum.
+                const v2f anx = half_pair_minus(neg_x ? u0.w : u0.x, org.x) * ix, afx = half_pair_minus(neg_x ? u0.x : u0.w, org.x) * ix;
+                const v2f any = half_pair_minus(neg_y ? u1.x : u0.y, org.y) * iy, afy = half_pair_minus(neg_y ? u0.y : u1.x, org.y) * iy;
+                const v2f anz = half_pair_minus(neg_z ? u1.y : u0.z, org.z) * iz, afz = half_pair_minus(neg_z ? u0.z : u1.y, org.z) * iz;
+                const v2f bnx = half_pair_minus(neg_x ? u2.y : u1.z, org.x) * ix, bfx = half_pair_minus(neg_x ? u1.z : u2.y, org.x) * ix;
+                const v2f bny = half_pair_minus(neg_y ? u2.z : u1.w, org.y) * iy, bfy = half_pair_minus(neg_y ? u1.w : u2.z, org.y) * iy;
+                const v2f bnz = half_pair_minus(neg_z ? u2.w : u2.x, org.z) * iz, bfz = half_pair_minus(neg_z ? u2.x : u2.w, org.z) * iz;
+                const float tn0 = vmax3(anx.x, any.x, anz.x), tx0 = vmin3(afx.x, afy.x, afz.x);
+                const float tn1 = vmax3(anx.y, any.y, anz.y), tx1 = vmin3(afx.y, afy.y, afz.y);
+                const float tn2 = vmax3(bnx.x, bny.x, bnz.x), tx2 = vmin3(bfx.x, bfy.x, bfz.x);
+                const float tn3 = vmax3(bnx.y, bny.y, bnz.y), tx3 = vmin3(bfx.y, bfy.y, bfz.y);
                 const bool hit0 = !(tx0 < vmax(tn0, lim)) && (tn0 < best.t);
                 const bool hit1 = !(tx1 < vmax(tn1, lim)) && (tn1 < best.t);
                 const bool hit2 = !(tx2 < vmax(tn2, lim)) && (tn2 < best.t);
