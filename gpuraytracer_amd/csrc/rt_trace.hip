@@ -6,18 +6,20 @@
 // texel indices, the seed of a ray is a function of its global index.
 //
 // What is new is how the work is laid out:
-//  * The reference keeps a 48-entry stack of node indices in private memory. The hierarchy it builds
-//    is a balanced implicit tree whose shape depends only on the primitive count (children of node i
-//    of level k are nodes 2i, 2i+1 of level k-1), so the same left-first depth-first order is walked
-//    here with two registers (level, index) and no stack: "pop" = climb past every right child (the
-//    trailing one bits of the index) and every only child, then step to the sibling. The order of box
-//    and triangle tests, hence the closest hit and its tie-breaking, is exactly the reference's.
-//  * The reference runs one thread per ray through traversal and shading. Here traversal is a
-//    persistent kernel: waves pull ray indices from an atomic queue (one aggregated atomic per wave
-//    refill) and refill finished lanes, so a wave never idles behind its longest ray; a lane that
-//    reaches a leaf parks until enough lanes of its wave are parked, so the expensive triangle tests
-//    run with many lanes active; closest hits go to a 20-byte record and a second, fully
-//    convergent kernel shades them.
+//  * The reference keeps a 48-entry stack of node indices in private memory. The hierarchy it builds is a balanced
+//    implicit tree whose shape depends only on the primitive count, so the same left-first depth-first order is
+//    walked here without a stack: nodes are numbered as in a complete binary tree (the node in slot h has its
+//    children in slots 2h and 2h + 1), and the nodes still to be visited are a few bits per level in a register.
+//    The order of the triangle tests, hence the closest hit and its tie-breaking, is exactly the reference's.
+//  * The reference runs one thread per ray through traversal and shading. Here traversal is a persistent kernel:
+//    waves pull ray indices from atomic queues and refill finished lanes, so a wave never idles behind its longest
+//    ray; a lane that reaches a leaf notes it in a first-in first-out list and walks on, and the triangle tests
+//    run when enough lanes have one waiting; closest hits go to a 20-byte record and a second, fully convergent
+//    kernel shades them.
+//  * Three traversal kernels give the same buffers: k_traverse_quad (the default: two levels per step on 64-byte
+//    records of widened binary16 boxes, exact re-test at the leaves), k_traverse (one level per step on exact
+//    sibling pairs; its counting variant reproduces the reference's box-test count), k_trace (one thread per ray;
+//    also the brute-force path without a hierarchy).
 //
 // Arithmetic conventions are those of rt_math.h; the slab test multiplies by one IEEE reciprocal of
 // each direction component per ray instead of dividing per box.
