@@ -409,10 +409,18 @@ __device__ __forceinline__ void intersect_leaf(f3 o, f3 d, float4 l0, float4 l1,
     const v2f uv = u + v;
     h0.w = rintf(fabsf(det.x) * inv.x);
     h1.w = rintf(fabsf(det.y) * inv.y);
-    if (t.x < 1e-6f || u.x < 0.0f || v.x < 0.0f || uv.x > 1.0f) { h0.t = -1.0f; h0.u = -1.0f; h0.v = -1.0f; }
-    else { h0.t = t.x; h0.u = u.x; h0.v = v.x; }
-    if (t.y < 1e-6f || u.y < 0.0f || v.y < 0.0f || uv.y > 1.0f) { h1.t = -1.0f; h1.u = -1.0f; h1.v = -1.0f; }
-    else { h1.t = t.y; h1.u = u.y; h1.v = v.y; }
+    const bool out0 = t.x < 1e-6f || u.x < 0.0f || v.x < 0.0f || uv.x > 1.0f;
+    const bool out1 = t.y < 1e-6f || u.y < 0.0f || v.y < 0.0f || uv.y > 1.0f;
+    h0.t = out0 ? -1.0f : t.x; h0.u = out0 ? -1.0f : u.x; h0.v = out0 ? -1.0f : v.x;
+    h1.t = out1 ? -1.0f : t.y; h1.u = out1 ? -1.0f : u.y; h1.v = out1 ? -1.0f : v.y;
+}
+
+// check_hit() without a branch; wanted = the leaf's triangle is to be tested at all
+__device__ __forceinline__ void check_hit_select(bool wanted, const Hit& h, float tmin, float tmax, uint32_t ci, Hit& best,
+                                                 uint32_t& best_ci) {
+    const bool use = wanted && (tmin <= h.t) && (tmax > h.t) && (h.t < best.t);
+    best.t = use ? h.t : best.t; best.u = use ? h.u : best.u; best.v = use ? h.v : best.v; best.w = use ? h.w : best.w;
+    best_ci = use ? ci : best_ci;
 }
 
 // The walk runs on the private copy of the hierarchy: the node in slot h (trunk: 1) has the 64-byte record of
@@ -832,13 +840,14 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
                 if (__uint_as_float(e.y) < best.t) {
                     const float4* t = reinterpret_cast<const float4*>(leaf_bytes + e.x * 128u);
                     const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
-                    if (leaf_box_passes(org, inv_d, lim, best.t, l0, l1, l2, l3, l4)) {
-                        const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
-                        Hit h0, h1;
-                        intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
-                        check_hit(h0, tmin_r, tmax_r, ci0, best, best_ci);
-                        if (ci1 != 0xffffffffu) check_hit(h1, tmin_r, tmax_r, ci1, best, best_ci);
-                    }
+                    // one straight run of instructions for every lane that has come this far: a leaf whose exact box
+                    // fails is rare, and branches would cost more than they save
+                    const bool wanted = leaf_box_passes(org, inv_d, lim, best.t, l0, l1, l2, l3, l4);
+                    const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
+                    Hit h0, h1;
+                    intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
+                    check_hit_select(wanted, h0, tmin_r, tmax_r, ci0, best, best_ci);
+                    check_hit_select(wanted && ci1 != 0xffffffffu, h1, tmin_r, tmax_r, ci1, best, best_ci);
                 }
             }
         }
