@@ -991,7 +991,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     // the traversal kernel is a device setting (rt_device_set_trace_kernel); the other knobs are read once
     const bool simple_kernel = dev->trace_kernel == RT_TRACE_KERNEL_SIMPLE;
     const bool quad_kernel = dev->trace_kernel == RT_TRACE_KERNEL_QUAD;
-    static const uint32_t leaf_threshold = env_u32("GPURT_LEAF_THRESHOLD", 12u);
+    static const uint32_t leaf_threshold = env_u32("GPURT_LEAF_THRESHOLD", 16u);
     static const uint32_t blocks_per_cu = env_u32("GPURT_BLOCKS_PER_CU", 4u);
     static const uint32_t sort_rays = env_u32("GPURT_SORT_RAYS", 1u);
 
