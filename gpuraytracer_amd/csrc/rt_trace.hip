@@ -863,8 +863,8 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
 
 // Key of every ray for the order the traversal queues hand rays out in (the reference has no such step; the
 // order rays are traced in does not enter any result).
-//  * Major part, descending: an estimate of the walk's length - how many of the nodes at one depth near the
-//    trunk the ray's segment touches. Walk lengths are spread over three orders of magnitude, and a launch ends
+//  * Major part, descending: an estimate of the walk's length - how many of a sample of the nodes at one depth
+//    the ray's segment touches. Walk lengths are spread over three orders of magnitude, and a launch ends
 //    with its longest walks; handing those out first keeps all lanes busy to the end.
 //  * Minor part: locality - rays that start in the same cell of a 16^3 grid over the trunk's box and point
 //    into the same of 4^3 direction cells get neighbouring queue positions.
@@ -878,8 +878,8 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {      // abcd -> a00b00
 }
 __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float4* __restrict__ rays,
                                                   const float4* __restrict__ nodes, const float4* __restrict__ pairs,
-                                                  uint32_t first_record, uint32_t num_records, uint32_t cost_shift,
-                                                  uint32_t cost_major_bits, uint2* __restrict__ keys) {
+                                                  uint32_t first_record, uint32_t num_records, uint32_t record_stride,
+                                                  uint32_t cost_shift, uint32_t cost_major_bits, uint2* __restrict__ keys) {
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     if (tid >= num_rays) return;
     const float4 lo = nodes[0], hi = nodes[1];
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float
     const f3 org = mk(r0.x, r0.y, r0.z), dir = mk(r0.w, r1.x, r1.y);
     const f3 inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     uint32_t touched = 0u;
-    for (uint32_t j = 0u; j < num_records; j++) {
+    for (uint32_t j = 0u; j < num_records; j += record_stride) {
         const float4* rec = pairs + 4 * (size_t)(first_record + j);
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         float bt0, bt1;
@@ -1077,14 +1077,17 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     }
     uint2* order = nullptr;
     if (sort_rays) {
-        // walk-length estimate from the nodes at depth 8 (or the deepest level above the leaves of a small tree)
+        // walk-length estimate from every fourth pair of nodes at depth 10 (or the deepest level above the leaves of a
+        // small tree): deeper, smaller boxes tell long walks from short ones better than all the boxes of depth 8 do
         const uint32_t root_level = p.lv.count - 1u;
-        const uint32_t depth = root_level > 8u ? 8u : (root_level > 1u ? root_level - 1u : 1u);
+        static const uint32_t probe_depth = env_u32("GPURT_COST_DEPTH", 10u) < 2u ? 2u : env_u32("GPURT_COST_DEPTH", 10u);
+        const uint32_t depth = root_level > probe_depth ? probe_depth : (root_level > 1u ? root_level - 1u : 1u);
         const uint32_t nodes_there = p.lv.n[root_level - depth];
+        static const uint32_t probe_stride = env_u32("GPURT_COST_STRIDE", 4u) < 1u ? 1u : env_u32("GPURT_COST_STRIDE", 4u);
         uint32_t cost_shift = 0u;
-        while ((nodes_there >> cost_shift) > 63u) cost_shift++;
+        while (((nodes_there / probe_stride) >> cost_shift) > 63u) cost_shift++;
         hipLaunchKernelGGL(k_ray_keys, grid, block, 0, s, nr, ray_in, nodes, pairs, 1u << (depth - 1u), (nodes_there + 1u) / 2u,
-                           cost_shift, cost_major_bits, dev->ray_keys_a);
+                           probe_stride, cost_shift, cost_major_bits, dev->ray_keys_a);
         rc = rt_sort_pairs(dev, dev->ray_keys_a, dev->ray_keys_b, nr, 3u, &order);      // 24-bit keys
         if (rc) return rc;
     }
