@@ -840,14 +840,18 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
                 if (__uint_as_float(e.y) < best.t) {
                     const float4* t = reinterpret_cast<const float4*>(leaf_bytes + e.x * 128u);
                     const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
-                    // one straight run of instructions for every lane that has come this far: a leaf whose exact box
-                    // fails is rare, and branches would cost more than they save
-                    const bool wanted = leaf_box_passes(org, inv_d, lim, best.t, l0, l1, l2, l3, l4);
+                    // Both triangles first, in one straight run of instructions. The leaf's exact box only matters if one
+                    // of them would become the closest hit, which few leaves see: only then is the box worked out.
                     const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
                     Hit h0, h1;
                     intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
-                    check_hit_select(wanted, h0, tmin_r, tmax_r, ci0, best, best_ci);
-                    check_hit_select(wanted && ci1 != 0xffffffffu, h1, tmin_r, tmax_r, ci1, best, best_ci);
+                    const bool may0 = (tmin_r <= h0.t) && (tmax_r > h0.t) && (h0.t < best.t);
+                    const bool may1 = (ci1 != 0xffffffffu) && (tmin_r <= h1.t) && (tmax_r > h1.t) && (h1.t < best.t);
+                    if (may0 || may1) {
+                        const bool wanted = leaf_box_passes(org, inv_d, lim, best.t, l0, l1, l2, l3, l4);
+                        check_hit_select(wanted, h0, tmin_r, tmax_r, ci0, best, best_ci);
+                        check_hit_select(wanted && ci1 != 0xffffffffu, h1, tmin_r, tmax_r, ci1, best, best_ci);
+                    }
                 }
             }
         }
@@ -879,7 +883,7 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {      // abcd -> a00b00
 __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float4* __restrict__ rays,
                                                   const float4* __restrict__ nodes, const float4* __restrict__ pairs,
                                                   uint32_t first_record, uint32_t num_records, uint32_t record_stride,
-                                                  uint32_t cost_shift, uint32_t cost_major_bits, uint2* __restrict__ keys) {
+                                                  uint32_t cost_shift, uint32_t cost_bits, uint2* __restrict__ keys) {
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     if (tid >= num_rays) return;
     const float4 lo = nodes[0], hi = nodes[1];
@@ -894,7 +898,8 @@ __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float
         slab_pair(org, inv_d, r1.z, r1.w, q0, q1, q2, bt0, bt1);
         touched += (bt0 != 1e30f ? 1u : 0u) + ((q0.y == q0.y) && (bt1 != 1e30f) ? 1u : 0u);
     }
-    const uint32_t cost_class = min(touched >> cost_shift, 63u);
+    const uint32_t top_class = (1u << cost_bits) - 1u;
+    const uint32_t cost_class = min(touched >> cost_shift, top_class);
     const float cx = (r0.x - lo.x) / (lo.w - lo.x), cy = (r0.y - lo.y) / (hi.x - lo.y), cz = (r0.z - lo.z) / (hi.y - lo.z);
     const uint32_t ox = (uint32_t)fminf(fmaxf(cx * 16.0f, 0.0f), 15.0f);
     const uint32_t oy = (uint32_t)fminf(fmaxf(cy * 16.0f, 0.0f), 15.0f);
@@ -904,10 +909,8 @@ __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float
     const uint32_t dz = (uint32_t)fminf(fmaxf(r1.y * 2.0f + 2.0f, 0.0f), 3.0f);
     const uint32_t okey = spread3(ox) | (spread3(oy) << 1) | (spread3(oz) << 2);      // 12 bits
     const uint32_t dkey = spread3(dx) | (spread3(dy) << 1) | (spread3(dz) << 2);      // 6 bits
-    // the top cost_major_bits of the (descending) cost class lead the key, the rest of it ends the key
-    const uint32_t cinv = 63u - cost_class, minor_bits = 6u - cost_major_bits;
-    const uint32_t major = cinv >> minor_bits, minor = cinv & ((1u << minor_bits) - 1u);
-    keys[tid] = make_uint2((((major << 18) | (okey << 6) | dkey) << minor_bits) | minor, tid);
+    // 24 bits: the (descending) cost class leads, the locality bits that still fit follow
+    keys[tid] = make_uint2(((top_class - cost_class) << (24u - cost_bits)) | (((okey << 6) | dkey) >> (cost_bits - 6u)), tid);
 }
 
 __global__ __launch_bounds__(256) void k_shade(TraceParams p, ShadeBuffers b, const float4* __restrict__ hit_records,
@@ -1010,7 +1013,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     p.num_textures = (uint32_t)(texture_ids->bytes / sizeof(rt_texture_id));
     p.leaf_threshold = leaf_threshold < 1u ? 1u : (leaf_threshold > 64u ? 64u : leaf_threshold);
     static const uint32_t deal_shift_env = env_u32("GPURT_DEAL_SHIFT", 6u);
-    static const uint32_t cost_major_bits = env_u32("GPURT_COST_BITS", 6u) > 6u ? 6u : env_u32("GPURT_COST_BITS", 6u);
+    static const uint32_t cost_bits = env_u32("GPURT_COST_BITS", 6u) < 6u ? 6u : (env_u32("GPURT_COST_BITS", 6u) > 12u ? 12u : env_u32("GPURT_COST_BITS", 6u));
     static const uint32_t refill_threshold = env_u32("GPURT_REFILL_THRESHOLD", 16u);
     p.refill_threshold = refill_threshold < 1u ? 1u : (refill_threshold > 64u ? 64u : refill_threshold);
     p.deal_shift = deal_shift_env < 6u ? 6u : (deal_shift_env > 20u ? 20u : deal_shift_env);
@@ -1085,9 +1088,9 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         const uint32_t nodes_there = p.lv.n[root_level - depth];
         static const uint32_t probe_stride = env_u32("GPURT_COST_STRIDE", 4u) < 1u ? 1u : env_u32("GPURT_COST_STRIDE", 4u);
         uint32_t cost_shift = 0u;
-        while (((nodes_there / probe_stride) >> cost_shift) > 63u) cost_shift++;
+        while (((nodes_there / probe_stride) >> cost_shift) > (1u << cost_bits) - 1u) cost_shift++;
         hipLaunchKernelGGL(k_ray_keys, grid, block, 0, s, nr, ray_in, nodes, pairs, 1u << (depth - 1u), (nodes_there + 1u) / 2u,
-                           probe_stride, cost_shift, cost_major_bits, dev->ray_keys_a);
+                           probe_stride, cost_shift, cost_bits, dev->ray_keys_a);
         rc = rt_sort_pairs(dev, dev->ray_keys_a, dev->ray_keys_b, nr, 3u, &order);      // 24-bit keys
         if (rc) return rc;
     }
