@@ -191,6 +191,36 @@ __global__ __launch_bounds__(256) void k_morton_packed(SceneBounds sb, const flo
     keys[t] = make_uint2(code, ci);
 }
 
+// Keys of the library's own hierarchy, and every triangle's place in the reference's order: entry r of the
+// sorted reference pairs names triangle ci / 3; its key is the interleave of the same ten bits per axis the
+// reference quantises the centroid to (CS_GenerateMortonCodes.hlsl:58-66), without the overlap of the reference's
+// bit spreading.
+__device__ __forceinline__ uint32_t spread_bits3(uint32_t v) {
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ __launch_bounds__(256) void k_spatial_keys(SceneBounds sb, const float* __restrict__ dbounds, uint32_t n,
+                                                      const uint2* __restrict__ sorted, const float4* __restrict__ tris,
+                                                      uint2* __restrict__ keys, uint32_t* __restrict__ ranks) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n) return;
+    if (dbounds) {
+        sb.mn[0] = dbounds[0]; sb.mn[1] = dbounds[1]; sb.mn[2] = dbounds[2];
+        sb.mx[0] = dbounds[4]; sb.mx[1] = dbounds[5]; sb.mx[2] = dbounds[6];
+    }
+    const uint32_t ci = sorted[r].y;
+    const float4 a = tris[ci], b = tris[ci + 1], c = tris[ci + 2];
+    const float cx = 0.333333f * ((a.x + b.x) + c.x), cy = 0.333333f * ((a.y + b.y) + c.y), cz = 0.333333f * ((a.z + b.z) + c.z);
+    const float qx = saturatef((cx - sb.mn[0]) / (sb.mx[0] - sb.mn[0])) * 1023.0f;
+    const float qy = saturatef((cy - sb.mn[1]) / (sb.mx[1] - sb.mn[1])) * 1023.0f;
+    const float qz = saturatef((cz - sb.mn[2]) / (sb.mx[2] - sb.mn[2])) * 1023.0f;
+    keys[r] = make_uint2((spread_bits3((uint32_t)qz) << 2) | (spread_bits3((uint32_t)qy) << 1) | spread_bits3((uint32_t)qx), ci);
+    ranks[ci / 3u] = r;
+}
+
 __global__ __launch_bounds__(256) void k_expand_keys(uint32_t n, const uint2* __restrict__ keys, uint4* __restrict__ morton) {
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t < n) { uint2 k = keys[t]; morton[t] = make_uint4(k.x, k.y, 0u, 0u); }
@@ -910,9 +940,10 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
     a->dev = dev;
     a->max_prims = max_primitives;
     a->num_prims = 0;
-    a->tris = a->sorted_tris = a->quads = nullptr;
+    a->tris = a->sorted_tris = a->quads = a->sp_quads = a->sp_tris = nullptr;
     a->keys_a = a->keys_b = nullptr;
-    a->pairs = nullptr;
+    a->pairs = a->sp_pairs = a->sp_nodes = nullptr;
+    a->ranks = nullptr;
     const size_t tri_bytes = (size_t)max_primitives * 48u, key_bytes = (size_t)max_primitives * 8u;
     hipError_t e = hipMalloc((void**)&a->tris, tri_bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&a->sorted_tris, ((size_t)max_primitives + 1u) / 2u * RT_LEAF_STRIDE * sizeof(float4));
@@ -924,7 +955,12 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
         // a smaller scene packed later never needs more slots than the largest one
         if (e == hipSuccess) e = hipMalloc((void**)&a->pairs, (rt_aligned_node_slots(&lv) + 64u) * sizeof(rt_aabb));
         if (e == hipSuccess) e = hipMalloc((void**)&a->quads, rt_quad_records(&lv) * RT_QUAD_STRIDE * sizeof(float4));
+        if (e == hipSuccess) e = hipMalloc((void**)&a->sp_pairs, (rt_aligned_node_slots(&lv) + 64u) * sizeof(rt_aabb));
+        if (e == hipSuccess) e = hipMalloc((void**)&a->sp_quads, rt_quad_records(&lv) * RT_QUAD_STRIDE * sizeof(float4));
     }
+    if (e == hipSuccess) e = hipMalloc((void**)&a->sp_nodes, (size_t)rt_bvh_node_count(max_primitives) * sizeof(rt_aabb));
+    if (e == hipSuccess) e = hipMalloc((void**)&a->sp_tris, ((size_t)max_primitives + 1u) / 2u * RT_LEAF_STRIDE * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&a->ranks, (size_t)max_primitives * sizeof(uint32_t));
     if (e != hipSuccess) {
         rt_accel_destroy(a);
         return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
@@ -943,6 +979,11 @@ int rt_accel_destroy(rt_accel* a) {
     if (a->keys_a) (void)hipFree(a->keys_a);
     if (a->keys_b) (void)hipFree(a->keys_b);
     if (a->pairs) (void)hipFree(a->pairs);
+    if (a->sp_nodes) (void)hipFree(a->sp_nodes);
+    if (a->sp_pairs) (void)hipFree(a->sp_pairs);
+    if (a->sp_quads) (void)hipFree(a->sp_quads);
+    if (a->sp_tris) (void)hipFree(a->sp_tris);
+    if (a->ranks) (void)hipFree(a->ranks);
     delete a;
     return RT_OK;
 }
@@ -1065,6 +1106,18 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
         hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, a->pairs, a->quads);
     if (morton_codes)
         hipLaunchKernelGGL(k_expand_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, n, src, (uint4*)morton_codes->ptr);
+
+    // the library's own hierarchy: same triangles, same kernels, keys without overlapping bits
+    uint2* other = src == a->keys_a ? a->keys_b : a->keys_a;
+    hipLaunchKernelGGL(k_spatial_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, make_bounds(scene_min, scene_max), dbounds, n, src,
+                       a->tris, other, a->ranks);
+    uint2* sp_src = nullptr;
+    rc = rt_sort_pairs(dev, other, src, n, 4u, &sp_src);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)sp_src,
+                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, a->sp_pairs, a->sp_quads);
+    for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
+        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, a->sp_nodes, a->sp_pairs, a->sp_quads);
     return rt_launch_status();
 }
 

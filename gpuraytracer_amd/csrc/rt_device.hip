@@ -33,14 +33,17 @@ int rt_device_create(int gpu_index, rt_device** out) {
     d->bounds_partials = nullptr;
     d->ray_keys_a = nullptr;
     d->ray_keys_b = nullptr;
+    d->listed_rays = nullptr;
     d->conv_pairs = nullptr;
     d->conv_tris = nullptr;
     d->conv_quads = nullptr;
     d->conv_capacity = 0;
-    {   // initial choice of the traversal kernel: GPURT_TRACE_KERNEL = quad (default) | wave | simple
+    {   // initial choice of the traversal kernel: GPURT_TRACE_KERNEL = spatial (default) | quad | wave | simple
         const char* v = std::getenv("GPURT_TRACE_KERNEL");
-        d->trace_kernel = (v && !std::strcmp(v, "wave")) ? RT_TRACE_KERNEL_WAVE : (v && !std::strcmp(v, "simple")) ? RT_TRACE_KERNEL_SIMPLE
-                                                                                                                 : RT_TRACE_KERNEL_QUAD;
+        d->trace_kernel = (v && !std::strcmp(v, "quad"))     ? RT_TRACE_KERNEL_QUAD
+                          : (v && !std::strcmp(v, "wave"))   ? RT_TRACE_KERNEL_WAVE
+                          : (v && !std::strcmp(v, "simple")) ? RT_TRACE_KERNEL_SIMPLE
+                                                             : RT_TRACE_KERNEL_SPATIAL;
     }
     d->time_traverse = false;
     d->timing_events = nullptr;
@@ -66,6 +69,7 @@ int rt_device_destroy(rt_device* dev) {
     if (dev->bounds_partials) (void)hipFree(dev->bounds_partials);
     if (dev->ray_keys_a) (void)hipFree(dev->ray_keys_a);
     if (dev->ray_keys_b) (void)hipFree(dev->ray_keys_b);
+    if (dev->listed_rays) (void)hipFree(dev->listed_rays);
     if (dev->conv_pairs) (void)hipFree(dev->conv_pairs);
     if (dev->conv_tris) (void)hipFree(dev->conv_tris);
     if (dev->conv_quads) (void)hipFree(dev->conv_quads);

@@ -20,7 +20,8 @@ struct rt_device {
     float4* hit_records;       // [hit_capacity] (t, u, v, facing)
     uint32_t* hit_ci;          // [hit_capacity] first index slot of the hit triangle
     size_t hit_capacity;
-    uint32_t* queue_counter;   // ray queue heads of the persistent traversal kernel (256 bytes)
+    uint32_t* queue_counter;   // ray queue heads of the two traversal launches (256 bytes each), length of the list between them
+    uint2* listed_rays;        // [hit_capacity] (0, ray index): rays the second traversal launch walks again
     uint2* ray_keys_a;         // [hit_capacity] (locality key, ray index) pairs: the order rays are handed out in
     uint2* ray_keys_b;
     // private copy of the hierarchy for trace calls that come without an accel (rebuilt by every such call)
@@ -58,6 +59,14 @@ struct rt_accel {
     rt_aabb* pairs;            // private copy of the hierarchy as interleaved sibling pairs (rt_levels::aoff placement)
     uint2* keys_a;             // [max_prims] (code, 3*tri)
     uint2* keys_b;             // [max_prims]
+    // The library's own hierarchy over the same triangles (same kernels, same shape, codes whose bits do not
+    // overlap), for the traversal that does not follow the reference's order: nodes, sibling pairs, records of
+    // four grandchildren, leaves; and every triangle's place in the reference's order.
+    rt_aabb* sp_nodes;
+    rt_aabb* sp_pairs;
+    float4* sp_quads;
+    float4* sp_tris;
+    uint32_t* ranks;           // [max_prims]
 };
 
 #define RT_HIP(call)                                              \

@@ -683,13 +683,37 @@ __device__ __forceinline__ bool leaf_box_passes(f3 o, f3 inv_d, float lim, float
     return !(tf < vmax(tn, lim)) && (tn != 1e30f) && (tn < closest);
 }
 
+// the same test without the closest hit: the distance at which the ray enters the leaf's exact box, or +infinity
+// if the reference's test lets it pass by
+__device__ __forceinline__ float leaf_box_entry(f3 o, f3 inv_d, float lim, float4 l0, float4 l1, float4 l2, float4 l3, float4 l4) {
+    const float big = 1e30f, small = -1e30f;
+    const float mnx = vmin3(vmin3(l0.x, l0.y, l1.z), vmin3(l1.w, l3.x, l3.y), big);
+    const float mny = vmin3(vmin3(l0.z, l0.w, l2.x), vmin3(l2.y, l3.z, l3.w), big);
+    const float mnz = vmin3(vmin3(l1.x, l1.y, l2.z), vmin3(l2.w, l4.x, l4.y), big);
+    const float mxx = vmax3(vmax3(l0.x, l0.y, l1.z), vmax3(l1.w, l3.x, l3.y), small);
+    const float mxy = vmax3(vmax3(l0.z, l0.w, l2.x), vmax3(l2.y, l3.z, l3.w), small);
+    const float mxz = vmax3(vmax3(l1.x, l1.y, l2.z), vmax3(l2.w, l4.x, l4.y), small);
+    const v2f tx = (v2f{mnx, mxx} - v2f{o.x, o.x}) * v2f{inv_d.x, inv_d.x};
+    const v2f ty = (v2f{mny, mxy} - v2f{o.y, o.y}) * v2f{inv_d.y, inv_d.y};
+    const v2f tz = (v2f{mnz, mxz} - v2f{o.z, o.z}) * v2f{inv_d.z, inv_d.z};
+    const float tn = vmax3(vmin(tx.x, tx.y), vmin(ty.x, ty.y), vmin(tz.x, tz.y));
+    const float tf = vmin3(vmax(tx.x, tx.y), vmax(ty.x, ty.y), vmax(tz.x, tz.y));
+    return (!(tf < vmax(tn, lim)) && (tn != 1e30f)) ? tn : __builtin_inff();
+}
+
 __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const float4* __restrict__ rays, const float4* __restrict__ nodes,
                                                        const float4* __restrict__ pairs, const float4* __restrict__ quads,
                                                        const float4* __restrict__ sorted_tris, float4* __restrict__ hit_records,
                                                        uint32_t* __restrict__ hit_ci, uint32_t* __restrict__ queue,
-                                                       const uint2* __restrict__ order) {
+                                                       const uint2* __restrict__ order, const uint32_t* __restrict__ listed) {
     extern __shared__ uint32_t s_dyn[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (listed) {
+        // the rays are the first *listed entries of order: a list another kernel of the same stream has filled
+        p.num_rays = *listed;
+        const uint32_t deal_block = 1u << p.deal_shift;
+        p.queue_chunk = ((((p.num_rays + deal_block - 1u) >> p.deal_shift) + 7u) / 8u) * deal_block;
+    }
     const uint32_t root_level = p.lv.count - 1u;               // >= 2
     const uint32_t first_leaf = 1u << root_level;              // slot of leaf 0
     const uint32_t first_leaf_grandparent = first_leaf >> 2;   // nodes from this slot on have leaves as grandchildren
@@ -865,6 +889,244 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
     }
 }
 
+// ---- the walk on a hierarchy of the library's own ----
+//
+// The reference's hierarchy is what its Morton codes make it: codes whose bits overlap (CS_GenerateMortonCodes.hlsl:30-38)
+// put triangles from all over the scene next to each other, its boxes are large, and its walk tests thousands of
+// them per ray. What the reference's walk RETURNS, though, can be said without its hierarchy: it goes through the
+// leaves in their order (pairs of neighbours of the sorted triangles), tests a leaf's triangles if the leaf's box lets
+// the ray in before the closest hit so far, and keeps a hit that is strictly closer. Leaving aside box entries that lie
+// behind their own triangles' hits, that is: of all triangles whose leaf box (in the reference's pairing) lets the
+// ray in, the one with the smallest distance, the earlier in the reference's order among equal distances.
+// k_traverse_spatial finds that triangle on a second hierarchy, built by the same kernels from non-overlapping codes
+// of the same centroids (leaves: pairs of neighbours in THAT order), with the step of k_traverse_quad:
+//  * a box is entered while its entry distance does not exceed "reach" (not: is below the closest hit), so that
+//    hits at the same distance are all seen and the order of the reference decides between them;
+//  * for a triangle that is hit, the reference's leaf of it (its place in the reference's order / 2) is fetched and
+//    that leaf's box tested as the reference tests it; a triangle whose box there lets the ray in late - entry
+//    distance above the hit distance, by rounding or by a hit distance far off for a ray nearly in the triangle's
+//    plane - is kept with reach = that entry distance, and every other hit up to reach is remembered;
+//  * a ray for which the order of the reference's walk could matter (another hit between the closest hit and the
+//    entry of its box, or a closer hit whose box entry is beyond reach) goes on a list, and k_traverse_quad walks the
+//    listed rays again on the reference's hierarchy.
+// What stays out of reach of this argument is a triangle whose computed hit distance is closer than the closest hit
+// kept here although its boxes are entered beyond it: the reference may keep such a hit, this kernel never sees it.
+__global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const float4* __restrict__ rays, const float4* __restrict__ nodes,
+                                                       const float4* __restrict__ pairs, const float4* __restrict__ quads,
+                                                       const float4* __restrict__ sorted_tris, float4* __restrict__ hit_records,
+                                                       uint32_t* __restrict__ hit_ci, uint32_t* __restrict__ queue,
+                                                       const uint2* __restrict__ order, const float4* __restrict__ ref_tris,
+                                                       const uint32_t* __restrict__ ranks, uint2* __restrict__ flagged,
+                                                       uint32_t* __restrict__ flag_count) {
+    extern __shared__ uint32_t s_dyn[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t root_level = p.lv.count - 1u;               // >= 2
+    const uint32_t first_leaf = 1u << root_level;              // slot of leaf 0
+    const uint32_t first_leaf_grandparent = first_leaf >> 2;   // nodes from this slot on have leaves as grandchildren
+    const bool odd_first = (root_level & 1u) != 0u;
+    uint2* s_fifo = reinterpret_cast<uint2*>(s_dyn) + tid;     // [kFifo][256] waiting leaves, this lane's column
+    const float4 root_lo = nodes[0], root_hi = nodes[1];
+    const char* quad_bytes = reinterpret_cast<const char*>(quads);
+    const char* leaf_bytes = reinterpret_cast<const char*>(sorted_tris);
+    const char* ref_leaf_bytes = reinterpret_cast<const char*>(ref_tris);
+
+    uint32_t ray = 0u;                // index of the ray this lane is walking (while w < kIdle)
+    uint32_t w = kIdle;
+    f3 org = mk(0.0f, 0.0f, 0.0f), dir = org, inv_d = org;
+    f3 inv_w = org;                   // reciprocals used with the widened boxes: finite where the direction is zero
+    bool neg_x = false, neg_y = false, neg_z = false;      // the ray travels downwards on that axis
+    float tmin_r = 0.0f, tmax_r = 0.0f, lim = 0.0f;
+    Hit best;
+    best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
+    uint32_t best_ci = 0u;
+    // Beyond the closest hit: its place in the reference's order, the distance up to which boxes are still entered
+    // (the larger of the hit's distance and the entry distance of its leaf's box in the reference's hierarchy),
+    // the smallest distance of any other hit seen, and whether the ray has to be walked again in the reference's order.
+    uint32_t best_rank = 0xffffffffu;
+    float reach = 0.0f, runner_up = 0.0f;
+    bool have_hit = false, again = false;
+    uint32_t h = 1u;                  // slot of the entered node
+    unsigned long long trail = 0ull;
+    uint32_t wait_head = 0u;
+    uint32_t q = blockIdx.x & 7u, queues_tried = 0u;       // wave-uniform
+
+    for (;;) {
+        // 1. refill: every lane without a ray takes the next index; one atomic per wave (see k_traverse)
+        //    A refill stalls the whole wave for an atomic and two dependent loads, so it waits until several lanes are
+        //    free, unless nobody could walk meanwhile.
+        const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(w == kIdle);
+        if (need_mask && ((uint32_t)__popcll(need_mask) >= p.refill_threshold || !__builtin_amdgcn_ballot_w64(w <= kFifo - 4u))) {
+            if (queues_tried >= 8u) {
+                if (w == kIdle) w = kDry;
+            } else {
+                const uint32_t q_begin = q * p.queue_chunk;
+                const uint32_t q_end = q_begin + p.queue_chunk;
+                const uint32_t leader = (uint32_t)__builtin_ctzll(need_mask);
+                uint32_t base = 0u;
+                if (lane == leader) base = atomicAdd(queue + 8u * q, (uint32_t)__popcll(need_mask));
+                base = q_begin + (uint32_t)__shfl((int)base, (int)leader, 64);
+                if (base >= q_end) {                               // wave-uniform: this queue is empty
+                    q = (q + 1u) & 7u;
+                    queues_tried++;
+                } else if (w == kIdle) {
+                    const uint32_t mine = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+                    if (mine < q_end) {
+                        const uint32_t slot = mine - q_begin;
+                        const uint32_t pos = (((slot >> p.deal_shift) * 8u + q) << p.deal_shift) | (slot & ((1u << p.deal_shift) - 1u));
+                        if (pos < p.num_rays) {
+                            const uint32_t rid = order ? order[pos].y : pos;
+                            const float4 r0 = rays[2 * (size_t)rid], r1 = rays[2 * (size_t)rid + 1];
+                            org = mk(r0.x, r0.y, r0.z); dir = mk(r0.w, r1.x, r1.y);
+                            tmin_r = r1.z; tmax_r = r1.w;
+                            lim = (tmin_r > 0.0f) ? tmin_r : __uint_as_float(1u);
+                            inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                            inv_w = mk(dir.x == 0.0f ? copysignf(3.0e38f, inv_d.x) : inv_d.x, dir.y == 0.0f ? copysignf(3.0e38f, inv_d.y) : inv_d.y,
+                                       dir.z == 0.0f ? copysignf(3.0e38f, inv_d.z) : inv_d.z);
+                            neg_x = inv_w.x < 0.0f; neg_y = inv_w.y < 0.0f; neg_z = inv_w.z < 0.0f;
+                            best.t = tmax_r; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
+                            best_ci = 0u; best_rank = 0xffffffffu;
+                            reach = tmax_r; runner_up = __builtin_inff();
+                            have_hit = false; again = false;
+                            // the trunk is entered on any box hit
+                            bool walk = slab(org, inv_d, tmin_r, tmax_r, root_lo, root_hi) != 1e30f;
+                            h = 1u; trail = 0ull;
+                            if (walk && odd_first) {
+                                float bt0, bt1;
+                                slab_pair(org, inv_d, tmin_r, tmax_r, pairs[4], pairs[5], pairs[6], bt0, bt1);
+                                const bool hit0 = (bt0 != 1e30f) && (bt0 < best.t);
+                                const bool hit1 = (bt1 != 1e30f) && (bt1 < best.t);      // a missing child is NaNs: no hit
+                                walk = hit0 || hit1;
+                                h = hit0 ? 2u : 3u;
+                                trail = (hit0 && hit1) ? 8ull : 0ull;
+                            }
+                            if (walk) {
+                                ray = rid; w = 0u;
+                            } else {
+                                hit_records[rid] = make_float4(best.t, 0.0f, 0.0f, 0.0f);
+                                hit_ci[rid] = 0u;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (!__builtin_amdgcn_ballot_w64(w < kIdle)) {
+            if (!__builtin_amdgcn_ballot_w64(w != kDry)) break;       // queues empty and nothing in flight: the wave is done
+            continue;
+        }
+
+        // 2. walk until a triangle round is due, a lane has finished its ray, or nobody can walk
+        unsigned long long waiting_mask, walking_mask;
+        for (;;) {
+            if (w <= kFifo - 4u) {
+                const uint4* rec = reinterpret_cast<const uint4*>(quad_bytes + (h << 6));
+                const uint4 u0 = rec[0], u1 = rec[1], u2 = rec[2];
+                const v2f ix = {inv_w.x, inv_w.x}, iy = {inv_w.y, inv_w.y}, iz = {inv_w.z, inv_w.z};
+                // first pair (slots 4h, 4h + 1): dwords 0 - 5 = min x y z, max x y z; second pair: dwords 6 - 11.
+                // The plane a ray meets first on an axis is the minimum if it travels upwards, else the maximum.
+                const v2f anx = half_pair_minus(neg_x ? u0.w : u0.x, org.x) * ix, afx = half_pair_minus(neg_x ? u0.x : u0.w, org.x) * ix;
+                const v2f any = half_pair_minus(neg_y ? u1.x : u0.y, org.y) * iy, afy = half_pair_minus(neg_y ? u0.y : u1.x, org.y) * iy;
+                const v2f anz = half_pair_minus(neg_z ? u1.y : u0.z, org.z) * iz, afz = half_pair_minus(neg_z ? u0.z : u1.y, org.z) * iz;
+                const v2f bnx = half_pair_minus(neg_x ? u2.y : u1.z, org.x) * ix, bfx = half_pair_minus(neg_x ? u1.z : u2.y, org.x) * ix;
+                const v2f bny = half_pair_minus(neg_y ? u2.z : u1.w, org.y) * iy, bfy = half_pair_minus(neg_y ? u1.w : u2.z, org.y) * iy;
+                const v2f bnz = half_pair_minus(neg_z ? u2.w : u2.x, org.z) * iz, bfz = half_pair_minus(neg_z ? u2.x : u2.w, org.z) * iz;
+                const float tn0 = vmax3(anx.x, any.x, anz.x), tx0 = vmin3(afx.x, afy.x, afz.x);
+                const float tn1 = vmax3(anx.y, any.y, anz.y), tx1 = vmin3(afx.y, afy.y, afz.y);
+                const float tn2 = vmax3(bnx.x, bny.x, bnz.x), tx2 = vmin3(bfx.x, bfy.x, bfz.x);
+                const float tn3 = vmax3(bnx.y, bny.y, bnz.y), tx3 = vmin3(bfx.y, bfy.y, bfz.y);
+                const bool hit0 = !(tx0 < vmax(tn0, lim)) && (tn0 <= reach);
+                const bool hit1 = !(tx1 < vmax(tn1, lim)) && (tn1 <= reach);
+                const bool hit2 = !(tx2 < vmax(tn2, lim)) && (tn2 <= reach);
+                const bool hit3 = !(tx3 < vmax(tn3, lim)) && (tn3 <= reach);
+                const uint32_t m = (hit0 ? 1u : 0u) | (hit1 ? 2u : 0u) | (hit2 ? 4u : 0u) | (hit3 ? 8u : 0u);
+                if (h < first_leaf_grandparent && m != 0u) {
+                    trail = (trail << 4) | (unsigned long long)(m & (m - 1u));
+                    h = (h << 2) | (uint32_t)__builtin_ctz(m);
+                } else {
+                    if (h >= first_leaf_grandparent) {
+                        const uint32_t leaf0 = 4u * h - first_leaf;
+                        if (hit0) { s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0, __float_as_uint(tn0)); w++; }
+                        if (hit1) { s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0 + 1u, __float_as_uint(tn1)); w++; }
+                        if (hit2) { s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0 + 2u, __float_as_uint(tn2)); w++; }
+                        if (hit3) { s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0 + 3u, __float_as_uint(tn3)); w++; }
+                    }
+                    // back to the first noted node of the nearest level that has one, or the walk is over
+                    if (trail == 0ull) {
+                        w |= kOver;
+                    } else {
+                        const uint32_t z = (uint32_t)__builtin_ctzll(trail);
+                        const uint32_t up = z & ~3u;
+                        unsigned long long t2 = trail >> up;
+                        t2 &= t2 - 1ull;
+                        h = ((h >> (up >> 1)) & ~3u) | (z & 3u);
+                        trail = t2;
+                    }
+                }
+            }
+            waiting_mask = __builtin_amdgcn_ballot_w64((w & 15u) != 0u);
+            walking_mask = __builtin_amdgcn_ballot_w64(w <= kFifo - 4u);
+            if (!walking_mask || (uint32_t)__popcll(waiting_mask) >= p.leaf_threshold) break;
+            if ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(w >= kOver && w != kDry)) >= p.refill_threshold) break;
+        }
+
+        // 3. triangle round once enough lanes have a leaf waiting (or nobody can walk any more)
+        if (waiting_mask && ((uint32_t)__popcll(waiting_mask) >= p.leaf_threshold || !walking_mask)) {
+            if ((w & 15u) != 0u) {
+                const uint2 e = s_fifo[wait_head * 256u];
+                wait_head = (wait_head + 1u) & (kFifo - 1u);
+                w--;
+                if (__uint_as_float(e.y) <= reach) {
+                    const float4* t = reinterpret_cast<const float4*>(leaf_bytes + e.x * 128u);
+                    const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
+                    const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
+                    Hit h0, h1;
+                    intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
+                    const bool may0 = (tmin_r <= h0.t) && (tmax_r > h0.t) && (h0.t <= reach);
+                    const bool may1 = (ci1 != 0xffffffffu) && (tmin_r <= h1.t) && (tmax_r > h1.t) && (h1.t <= reach);
+                    if (may0 || may1) {
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const Hit hk = k ? h1 : h0;
+                            const uint32_t ck = k ? ci1 : ci0;
+                            if ((k ? may1 : may0) && hk.t <= reach) {
+                                // The reference tests this triangle only if the box of ITS leaf of the triangle lets
+                                // the ray in: that leaf is the pair of neighbours in the reference's order.
+                                const uint32_t rank = ranks[ck / 3u];
+                                const float4* rt = reinterpret_cast<const float4*>(ref_leaf_bytes + (rank >> 1) * 128u);
+                                const float entry = leaf_box_entry(org, inv_d, lim, rt[0], rt[1], rt[2], rt[3], rt[4]);
+                                if (entry < __builtin_inff()) {
+                                    const float far_end = fmaxf(entry, hk.t);
+                                    const bool closer = !have_hit || hk.t < best.t || (hk.t == best.t && rank < best_rank);
+                                    if (!closer) {
+                                        runner_up = fminf(runner_up, hk.t);
+                                    } else if (have_hit ? far_end <= reach : far_end < tmax_r) {
+                                        if (have_hit) runner_up = fminf(runner_up, best.t);
+                                        best = hk; best_ci = ck; best_rank = rank; reach = far_end; have_hit = true;
+                                    } else if (have_hit) {
+                                        again = true;          // a hit that is closer, behind a box entry that is not
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // 4. a finished ray leaves its closest hit behind and frees the lane
+        if (w == kOver) {
+            hit_records[ray] = make_float4(best.t, best.u, best.v, best.w);
+            hit_ci[ray] = best_ci;
+            // the closest hit lies before the entry of its leaf's box and another hit lies in between: which of
+            // them the reference keeps depends on the order it meets them in
+            if (have_hit && reach > best.t && runner_up <= reach) again = true;
+            if (again) flagged[atomicAdd(flag_count, 1u)] = make_uint2(0u, ray);
+            w = kIdle;
+        }
+    }
+}
+
 // Key of every ray for the order the traversal queues hand rays out in (the reference has no such step; the
 // order rays are traced in does not enter any result).
 //  * Major part, descending: an estimate of the walk's length - how many of a sample of the nodes at one depth
@@ -925,18 +1187,21 @@ __global__ __launch_bounds__(256) void k_shade(TraceParams p, ShadeBuffers b, co
 }
 
 int trace_workspace(rt_device* dev, uint32_t num_rays) {
-    if (!dev->queue_counter) RT_HIP(hipMalloc((void**)&dev->queue_counter, 256));
+    // 8 ray queues of the first traversal, 8 of the second (the listed rays), and the length of the list
+    if (!dev->queue_counter) RT_HIP(hipMalloc((void**)&dev->queue_counter, 1024));
     if (num_rays <= dev->hit_capacity) return RT_OK;
     RT_HIP(hipStreamSynchronize(dev->stream));
     if (dev->hit_records) { (void)hipFree(dev->hit_records); dev->hit_records = nullptr; }
     if (dev->hit_ci) { (void)hipFree(dev->hit_ci); dev->hit_ci = nullptr; }
     if (dev->ray_keys_a) { (void)hipFree(dev->ray_keys_a); dev->ray_keys_a = nullptr; }
     if (dev->ray_keys_b) { (void)hipFree(dev->ray_keys_b); dev->ray_keys_b = nullptr; }
+    if (dev->listed_rays) { (void)hipFree(dev->listed_rays); dev->listed_rays = nullptr; }
     dev->hit_capacity = 0;
     hipError_t e = hipMalloc((void**)&dev->hit_records, (size_t)num_rays * 16u);
     if (e == hipSuccess) e = hipMalloc((void**)&dev->hit_ci, (size_t)num_rays * 4u);
     if (e == hipSuccess) e = hipMalloc((void**)&dev->ray_keys_a, (size_t)num_rays * 8u);
     if (e == hipSuccess) e = hipMalloc((void**)&dev->ray_keys_b, (size_t)num_rays * 8u);
+    if (e == hipSuccess) e = hipMalloc((void**)&dev->listed_rays, (size_t)num_rays * 8u);
     if (e != hipSuccess) return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
     dev->hit_capacity = num_rays;
     return RT_OK;
@@ -993,7 +1258,8 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
 
     // the traversal kernel is a device setting (rt_device_set_trace_kernel); the other knobs are read once
     const bool simple_kernel = dev->trace_kernel == RT_TRACE_KERNEL_SIMPLE;
-    const bool quad_kernel = dev->trace_kernel == RT_TRACE_KERNEL_QUAD;
+    const bool spatial_kernel = dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL && accel && accel->sp_quads;
+    const bool quad_kernel = dev->trace_kernel == RT_TRACE_KERNEL_QUAD || dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL;
     static const uint32_t leaf_threshold = env_u32("GPURT_LEAF_THRESHOLD", 16u);
     static const uint32_t blocks_per_cu = env_u32("GPURT_BLOCKS_PER_CU", 4u);
     static const uint32_t sort_rays = env_u32("GPURT_SORT_RAYS", 1u);
@@ -1054,7 +1320,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
 
     rc = trace_workspace(dev, nr);
     if (rc) return rc;
-    RT_HIP(hipMemsetAsync(dev->queue_counter, 0, 256, s));
+    RT_HIP(hipMemsetAsync(dev->queue_counter, 0, 1024, s));
     // persistent grid: enough workgroups to fill every CU, never more than there are rays to hand out
     hipDeviceProp_t prop;
     static int cus = 0;
@@ -1065,6 +1331,8 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     // the walk runs on the private copy of the hierarchy; a call without an accel gets one made from its buffers
     const float4* pairs = nullptr;
     const float4* quads = nullptr;
+    const float4* key_nodes = nodes;      // the hierarchy the walk-length estimate is taken on
+    const float4* key_pairs = nullptr;
     if (accel) {
         pairs = (const float4*)accel->pairs;
         quads = (const float4*)accel->quads;
@@ -1089,7 +1357,10 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         static const uint32_t probe_stride = env_u32("GPURT_COST_STRIDE", 4u) < 1u ? 1u : env_u32("GPURT_COST_STRIDE", 4u);
         uint32_t cost_shift = 0u;
         while (((nodes_there / probe_stride) >> cost_shift) > (1u << cost_bits) - 1u) cost_shift++;
-        hipLaunchKernelGGL(k_ray_keys, grid, block, 0, s, nr, ray_in, nodes, pairs, 1u << (depth - 1u), (nodes_there + 1u) / 2u,
+        const bool on_spatial = spatial_kernel && !stats;
+        key_nodes = on_spatial ? (const float4*)accel->sp_nodes : nodes;
+        key_pairs = on_spatial ? (const float4*)accel->sp_pairs : pairs;
+        hipLaunchKernelGGL(k_ray_keys, grid, block, 0, s, nr, ray_in, key_nodes, key_pairs, 1u << (depth - 1u), (nodes_there + 1u) / 2u,
                            probe_stride, cost_shift, cost_bits, dev->ray_keys_a);
         rc = rt_sort_pairs(dev, dev->ray_keys_a, dev->ray_keys_b, nr, 3u, &order);      // 24-bit keys
         if (rc) return rc;
@@ -1117,9 +1388,19 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     // k_traverse_quad addresses its records and the leaves with 32-bit byte offsets
     const bool offsets_fit = rt_aligned_node_slots(&p.lv) * sizeof(rt_aabb) <= 0xffffffffull && (size_t)p.lv.n[0] * 128u <= 0xffffffffull;
     if (stats) RT_LAUNCH_TRAVERSE(true);
-    else if (quad_kernel && offsets_fit && p.lv.count >= 3u && quads)
+    else if (spatial_kernel && offsets_fit && p.lv.count >= 3u) {
+        // first the walk on the library's own hierarchy, then the reference's walk for the rays it has listed
+        uint32_t* listed = dev->queue_counter + 128;
+        hipLaunchKernelGGL(k_traverse_spatial, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in,
+                           (const float4*)accel->sp_nodes, (const float4*)accel->sp_pairs, (const float4*)accel->sp_quads,
+                           (const float4*)accel->sp_tris, dev->hit_records, dev->hit_ci, dev->queue_counter, order, st,
+                           (const uint32_t*)accel->ranks, dev->listed_rays, listed);
         hipLaunchKernelGGL(k_traverse_quad, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in, nodes, pairs, quads,
-                           st, dev->hit_records, dev->hit_ci, dev->queue_counter, order);
+                           st, dev->hit_records, dev->hit_ci, dev->queue_counter + 64, (const uint2*)dev->listed_rays,
+                           (const uint32_t*)listed);
+    } else if (quad_kernel && offsets_fit && p.lv.count >= 3u && quads)
+        hipLaunchKernelGGL(k_traverse_quad, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in, nodes, pairs, quads,
+                           st, dev->hit_records, dev->hit_ci, dev->queue_counter, order, (const uint32_t*)nullptr);
     else RT_LAUNCH_TRAVERSE(false);
 #undef RT_LAUNCH_TRAVERSE
     if (timing) RT_HIP(hipEventRecord(timing[1], s));
@@ -1140,7 +1421,7 @@ int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats) {
 }
 
 int rt_device_set_trace_kernel(rt_device* dev, int kernel) {
-    if (!dev || kernel < RT_TRACE_KERNEL_QUAD || kernel > RT_TRACE_KERNEL_SIMPLE) return RT_ERR_INVALID_ARGUMENT;
+    if (!dev || kernel < RT_TRACE_KERNEL_QUAD || kernel > RT_TRACE_KERNEL_SPATIAL) return RT_ERR_INVALID_ARGUMENT;
     dev->trace_kernel = kernel;
     return RT_OK;
 }
@@ -1166,6 +1447,17 @@ int rt_device_traverse_timing(rt_device* dev, double* total_ms, uint32_t* launch
     *total_ms = sum;
     *launches = dev->timing_count;
     dev->timing_count = 0;
+    return RT_OK;
+}
+
+int rt_device_listed_rays(rt_device* dev, uint32_t* count) {
+    if (!dev || !count) return RT_ERR_INVALID_ARGUMENT;
+    *count = 0u;
+    if (!dev->queue_counter) return RT_OK;        // nothing traced yet
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+    RT_HIP(hipMemcpyAsync(count, dev->queue_counter + 128, sizeof(uint32_t), hipMemcpyDeviceToHost, dev->stream));
+    RT_HIP(hipStreamSynchronize(dev->stream));
     return RT_OK;
 }
 

@@ -84,15 +84,24 @@ const char* rt_error_string(int code);
  * {box tests, triangle tests, rays that hit, rays} as four uint64 to it (a slower kernel variant); NULL turns
  * it off. The counts fix the algorithmic bytes per ray of a workload. */
 int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats);
-/* Which traversal kernel rt_trace_rays / rt_trace_rays_accel launch (no counterpart in the reference; results are
- * identical): QUAD (default) walks two levels of the hierarchy per step on 128-byte records, WAVE one level per step
- * (also used for hierarchies of fewer than three levels and while counters are on), SIMPLE is one thread per ray
- * through traversal and shading. The environment variable GPURT_TRACE_KERNEL = quad | wave | simple sets the
- * initial choice of a new device. */
+/* Which traversal kernel rt_trace_rays / rt_trace_rays_accel launch (no counterpart in the reference).
+ * QUAD, WAVE and SIMPLE walk the reference's hierarchy in the reference's order and return the reference's closest
+ * hit by construction: QUAD two levels per step on 64-byte records, WAVE one level per step (also used for
+ * hierarchies of fewer than three levels and while counters are on), SIMPLE one thread per ray through traversal
+ * and shading. SPATIAL (default; rt_trace_rays_accel only, elsewhere it means QUAD) finds the same closest hit on a
+ * second hierarchy that rt_accel_build makes from non-overlapping Morton codes, several times faster; rays for which
+ * the reference's order could decide are walked again by QUAD. It differs from the reference only where a triangle's
+ * computed hit distance is closer than the entry of every box around it by more than the closest hit found - see
+ * the kernel's description; no test scene has such a ray. The environment variable
+ * GPURT_TRACE_KERNEL = spatial | quad | wave | simple sets the initial choice of a new device. */
 #define RT_TRACE_KERNEL_QUAD 0
 #define RT_TRACE_KERNEL_WAVE 1
 #define RT_TRACE_KERNEL_SIMPLE 2
+#define RT_TRACE_KERNEL_SPATIAL 3
 int rt_device_set_trace_kernel(rt_device* dev, int kernel);
+/* Instrumentation (no counterpart in the reference): how many rays of the device's last trace call the SPATIAL
+ * kernel handed to the walk in the reference's order (0 after a call with another kernel). Waits for the stream. */
+int rt_device_listed_rays(rt_device* dev, uint32_t* count);
 /* Instrumentation (no counterpart in the reference): while enabled, every trace launch brackets its traversal
  * kernel with a pair of events on the device's stream. rt_device_traverse_timing waits for the pairs recorded
  * so far, returns the sum of their durations and their number, and forgets them. */

@@ -200,10 +200,10 @@ def test_camera_rays_match_oracle(device, oracle, w, h, rpp, dof):
         b.free()
 
 
-KERNEL_QUAD, KERNEL_WAVE, KERNEL_SIMPLE = 0, 1, 2      # RT_TRACE_KERNEL_*
+KERNEL_QUAD, KERNEL_WAVE, KERNEL_SIMPLE, KERNEL_SPATIAL = 0, 1, 2, 3      # RT_TRACE_KERNEL_*
 
 
-def _render_both(device, oracle, sc, w, h, calls, rpp=1, depth=3, use_bvh=True, use_accel=True, dof=0.0, kernel=KERNEL_QUAD):
+def _render_both(device, oracle, sc, w, h, calls, rpp=1, depth=3, use_bvh=True, use_accel=True, dof=0.0, kernel=KERNEL_SPATIAL):
     from gpuraytracer_amd import capi
     from gpuraytracer_amd.pipeline import Pipeline
     capi.check(device.lib.rt_device_set_trace_kernel(device.handle, kernel), "rt_device_set_trace_kernel")
@@ -219,7 +219,7 @@ def _render_both(device, oracle, sc, w, h, calls, rpp=1, depth=3, use_bvh=True, 
     try:
         gp.render(calls)
     finally:
-        device.lib.rt_device_set_trace_kernel(device.handle, KERNEL_QUAD)
+        device.lib.rt_device_set_trace_kernel(device.handle, KERNEL_SPATIAL)
     op.render(calls)
     out = (gp.output_image(), op.output(), gp.result_image(), op.result(),
            gp.emitted.download(np.float32, 4 * w * h * rpp).reshape(-1, 4), op.emitted(),
@@ -255,7 +255,7 @@ def test_traced_images_match_oracle(device, oracle, n, w, h, calls, use_accel):
 
 
 @pytest.mark.parametrize("n", [3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 1023, 1025, 2049])
-@pytest.mark.parametrize("use_accel,kernel", [(True, KERNEL_QUAD), (False, KERNEL_QUAD), (True, KERNEL_WAVE)])
+@pytest.mark.parametrize("use_accel,kernel", [(True, KERNEL_SPATIAL), (True, KERNEL_QUAD), (False, KERNEL_QUAD), (True, KERNEL_WAVE)])
 def test_small_and_odd_triangle_counts_trace_exactly(device, oracle, n, use_accel, kernel):
     """Every shape of the balanced hierarchy near its corner cases: two leaves, only children on several levels,
     counts just below, at and above powers of two. Rays that miss everything leave their pixel untouched."""
@@ -266,19 +266,64 @@ def test_small_and_odd_triangle_counts_trace_exactly(device, oracle, n, use_acce
     assert g[8]["rays_hit"] > 0, "some ray must hit"
 
 
-@pytest.mark.parametrize("kernel", [KERNEL_QUAD, KERNEL_WAVE, KERNEL_SIMPLE])
+@pytest.mark.parametrize("kernel", [KERNEL_SPATIAL, KERNEL_QUAD, KERNEL_WAVE, KERNEL_SIMPLE])
 @pytest.mark.parametrize("n", [20000, 40001])
 def test_every_trace_kernel_gives_the_oracle_image(device, oracle, kernel, n):
-    """The three traversal kernels (two levels per step, one level per step, one thread per ray) produce the same
-    buffers, bit for bit; 20000 and 40001 triangles have an even and an odd number of levels below the trunk."""
+    """The four traversal kernels (the library's own hierarchy; the reference's hierarchy two levels per step, one
+    level per step, one thread per ray) produce the same buffers, bit for bit; 20000 and 40001 triangles have an
+    even and an odd number of levels below the trunk."""
     g = _render_both(device, oracle, _scene(n), 128, 72, 6, kernel=kernel)
     for name, a, b in (("tone-mapped", g[0], g[1]), ("result", g[2], g[3]), ("emitted", g[4], g[5]), ("rays", g[6], g[7])):
         assert a.view(np.uint32).tobytes() == b.view(np.uint32).tobytes(), "%s differs with kernel %d" % (name, kernel)
 
 
+def _wall_scene(k, copies, seed=3):
+    """copies coincident walls of k x k axis-aligned squares (two triangles each) in the plane z = 2: every leaf box
+    is flat, every ray that hits has `copies` hits at the same distance, and rays through the squares' diagonals
+    and edges hit several triangles of one wall. The triangles are shuffled so that neither order sees a wall whole."""
+    from gpuraytracer_amd import scenes
+    from gpuraytracer_amd.capi import vertex_dtype
+    rng = np.random.RandomState(seed)
+    xs = np.linspace(-1.0, 1.0, k + 1).astype(np.float32)
+    tris = []
+    for c in range(copies):
+        for i in range(k):
+            for j in range(k):
+                a, b, cc, d = (xs[i], xs[j]), (xs[i + 1], xs[j]), (xs[i + 1], xs[j + 1]), (xs[i], xs[j + 1])
+                tris.append((a, b, cc))
+                tris.append((a, cc, d))
+    tris = np.array(tris, dtype=np.float32)                      # [T][3][2]
+    tris = tris[rng.permutation(len(tris))]
+    n = len(tris)
+    v = np.zeros(3 * n, dtype=vertex_dtype)
+    v["position"][:, :2] = tris.reshape(-1, 2)
+    v["position"][:, 2] = 2.0
+    v["normal"] = (0, 0, -1)
+    v["uv"] = rng.uniform(0, 1, (3 * n, 2)).astype(np.float32)
+    v["material_id"] = np.repeat(np.arange(n) % 8, 3)
+    idx = np.arange(3 * n, dtype=np.uint32)
+    atlas, ids = scenes.default_atlas()
+    smin, smax = scenes.centroid_bounds(v, idx)
+    cam = dict(position=(0.0, 0.0, -1.0), focus=(0.0, 0.0, 2.0), up=(0.0, 1.0, 0.0), fov=1.0, near_z=0.01, far_z=10000.0)
+    return dict(vertices=v, indices=idx, materials=scenes.synthetic_materials(), texture_ids=ids, atlas=atlas, scene_min=smin,
+                scene_max=smax, camera=cam, name="walls-%d-%d" % (k, copies))
+
+
+@pytest.mark.parametrize("k,copies", [(8, 1), (8, 3), (20, 2)])
+def test_equal_distances_and_flat_boxes_follow_the_reference_order(device, oracle, k, copies):
+    """Hits at exactly the same distance (coincident walls, shared edges) go to the triangle the reference's walk
+    meets first, and boxes without thickness enter at distances that round differently from their triangles' hits:
+    the walk on the library's own hierarchy must sort both out or hand the ray to the reference's walk."""
+    sc = _wall_scene(k, copies)
+    g = _render_both(device, oracle, sc, 128, 128, 4, depth=2, kernel=KERNEL_SPATIAL)
+    for name, a, b in (("tone-mapped", g[0], g[1]), ("result", g[2], g[3]), ("emitted", g[4], g[5]), ("rays", g[6], g[7])):
+        assert a.view(np.uint32).tobytes() == b.view(np.uint32).tobytes(), "%s differs" % name
+    assert g[8]["rays_hit"] > 0
+
+
 def test_invalid_trace_kernel_is_rejected(device):
     from gpuraytracer_amd import capi
-    assert device.lib.rt_device_set_trace_kernel(device.handle, 3) == capi.RT_ERR_INVALID_ARGUMENT
+    assert device.lib.rt_device_set_trace_kernel(device.handle, 4) == capi.RT_ERR_INVALID_ARGUMENT
     assert device.lib.rt_device_set_trace_kernel(device.handle, -1) == capi.RT_ERR_INVALID_ARGUMENT
 
 
@@ -537,6 +582,43 @@ def test_dynamic_scene_rebuild_matches_oracle(device, oracle, use_accel):
     assert gp.result_image().view(np.uint32).tobytes() == op.result().view(np.uint32).tobytes()
     gp.close()
     op.close()
+
+
+@pytest.mark.parametrize("n,w,h", [(1_000_000, 3840, 2160), (10_000_000, 1920, 1080)])
+def test_full_size_frames_agree_between_the_two_hierarchies(device, oracle, n, w, h):
+    """The benchmark's frame (1M triangles, 3840x2160, 4 bounces) and a 10M-triangle frame, traced once on the
+    library's own hierarchy and once by the walk in the reference's order, which returns the reference's closest
+    hits by construction: every buffer must be the same bit for bit. Tolerance stated for this comparison: none."""
+    from gpuraytracer_amd import capi, host_py
+    from gpuraytracer_amd.pipeline import Pipeline
+    sc = host_py.synthetic_scene(n)
+    cam = sc["camera"]
+    iv, ip = oracle.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], w / h, cam["near_z"], cam["far_z"])
+    calls, depth = 4, 4
+    got = []
+    listed = []
+    for kernel in (KERNEL_SPATIAL, KERNEL_QUAD):
+        capi.check(device.lib.rt_device_set_trace_kernel(device.handle, kernel), "rt_device_set_trace_kernel")
+        rs = iter(oracle.mt19937(1, 0, 6).reshape(-1, 3))
+        ts = iter(oracle.mt19937(2, 0, 3 * calls + 3).reshape(-1, 3))
+        gp = Pipeline(device, sc, w, h, iv, ip, rpp=1, depth=depth, raygen_seeds=lambda: next(rs), trace_seeds=lambda: next(ts))
+        try:
+            for _ in range(calls):
+                gp.render(1)
+                c = C.c_uint32(0)
+                capi.check(device.lib.rt_device_listed_rays(device.handle, C.byref(c)), "rt_device_listed_rays")
+                listed.append(c.value)
+        finally:
+            device.lib.rt_device_set_trace_kernel(device.handle, KERNEL_SPATIAL)
+        got.append((gp.result_image().copy(), gp.emitted.download(np.float32, 4 * w * h).copy(),
+                    gp.rays.download(np.float32, 8 * w * h).copy()))
+        gp.close()
+    print("rays handed to the walk in the reference's order, per trace call:", listed[:calls], "of", w * h)
+    assert listed[calls:] == [0] * calls
+    assert max(listed[:calls]) < w * h // 100, "the second walk is meant for the odd ray"
+    for a, b, name in zip(got[0], got[1], ("result", "emitted", "rays")):
+        assert a.view(np.uint32).tobytes() == b.view(np.uint32).tobytes(), "%s differs between the hierarchies" % name
+    assert got[0][0][..., :3].max() > 0.0
 
 
 def test_ten_million_triangle_build_properties(device, oracle):
