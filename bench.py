@@ -31,7 +31,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak
-BUILD_BYTES_PER_TRIANGLE = 252  # Morton 56 + sort 80 + leaves 68 + upper levels 48 (reference data layout)
+# Morton 56 + sort 80 + leaves 68 + upper levels 48 (reference data layout) for the reference's hierarchy, and the same
+# again for the library's own hierarchy (its keys are made from the sorted pairs and the packed triangles: 56 as well)
+BUILD_BYTES_PER_TRIANGLE = 2 * 252
 
 # HBM-side bytes of ONE k_traverse_quad launch of the default workload on one GPU, from the hardware-counter passes
 # committed as profiles/r1_c3_final_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in runs of their
@@ -39,7 +41,8 @@ BUILD_BYTES_PER_TRIANGLE = 252  # Morton 56 + sort 80 + leaves 68 + upper levels
 # the bytes exactly (scripts/calib_fetch.hip; the doubling the microarchitecture guide prescribes applies to wide
 # streaming reads, which this kernel does not issue). Counters cannot be read inside a timed run, so the figure is
 # carried here and reported only for the configuration it was measured on.
-MEASURED_TRAFFIC = {("c3", 1): {"fetch": 147772356.0e3, "write": 489338.2e3}}
+MEASURED_TRAFFIC = {("c3", 1, "spatial"): {"fetch": 6667519.6e3, "write": 463487.3e3, "source": "profiles/r1_c3_spatial_pmc_summary.txt"},
+                    ("c3", 1, "quad"): {"fetch": 147772356.0e3, "write": 489338.2e3, "source": "profiles/r1_c3_final_pmc_summary.txt"}}
 
 WORKLOADS = {
     # name: (triangles, width, height, rays/pixel, bounces, description)
@@ -69,6 +72,8 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-walk", action="store_true",
+                    help="skip the two extra frames traced by the walk in the reference's order (reported beside `value`)")
     ap.add_argument("--dynamic", action="store_true", help="move the triangles on the device before every rebuild (always on for c5)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: rays per pixel grow with the GPU count; strong: the frame is fixed")
@@ -112,7 +117,7 @@ def main():
     cam = scene["camera"]
     iv, ip = host_py.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], width / height, cam["near_z"],
                                      cam["far_z"])
-    total_frames = args.steps + args.warmup + 2
+    total_frames = args.steps + args.warmup + 6      # + the counting frame and the frames of the walk in the reference's order
     rs = iter(scenes.mt19937_raw(1, 3 * total_frames).reshape(-1, 3))
     ts = iter(scenes.mt19937_raw(2, 3 * total_frames * depth).reshape(-1, 3))
 
@@ -183,6 +188,26 @@ def main():
         build_ms = [a.elapsed_ms(b) for a, b in build_events]
         trace_ms = [a.elapsed_ms(b) for a, b in trace_events]
 
+        # the same frames by the walk in the reference's order (untimed for `value`; reported beside it)
+        ref_walk = None
+        kernel_name = os.environ.get("GPURT_TRACE_KERNEL", "") or "spatial"
+        if kernel_name == "spatial" and world == 1 and not args.no_reference_walk:
+            dev.lib.rt_device_set_trace_kernel(dev.handle, 0)        # RT_TRACE_KERNEL_QUAD
+            pipe.render(depth)
+            torch.cuda.synchronize()
+            dev.lib.rt_device_set_traverse_timing(dev.handle, 1)
+            t1 = time.perf_counter()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            ref_elapsed = time.perf_counter() - t1
+            rk_ms, rk_n = ctypes.c_double(0.0), ctypes.c_uint32(0)
+            dev.lib.rt_device_traverse_timing(dev.handle, ctypes.byref(rk_ms), ctypes.byref(rk_n))
+            dev.lib.rt_device_set_traverse_timing(dev.handle, 0)
+            dev.lib.rt_device_set_trace_kernel(dev.handle, 3)        # RT_TRACE_KERNEL_SPATIAL
+            ref_walk = {"kernel": "k_traverse_quad", "value": round(width * height * rpp * depth * 2 / ref_elapsed / 1e6, 3),
+                        "unit": "Mrays/s", "steps": 2, "avg_launch_ms": round(rk_ms.value / max(rk_n.value, 1), 4)}
+
         # exact traversal counters of one more frame (untimed, instrumented kernel variant)
         stats_buf = dev.alloc(32)
         dev.lib.rt_device_set_trace_stats(dev.handle, stats_buf.handle)
@@ -206,7 +231,8 @@ def main():
 
     tkey = (args.workload, world)
     plain = not (args.triangles or args.width or args.height or args.band or args.dynamic) and args.scaling == "weak"
-    traffic = MEASURED_TRAFFIC.get(tkey) if plain and os.environ.get("GPURT_TRACE_KERNEL", "quad") in ("", "quad") else None
+    traffic = MEASURED_TRAFFIC.get(tkey + (kernel_name,)) if plain else None
+    kernel_symbol = {"spatial": "k_traverse_spatial", "quad": "k_traverse_quad", "wave": "k_traverse", "simple": "k_trace"}.get(kernel_name, kernel_name)
     out = {
         "metric": "Mrays/sec", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
@@ -218,18 +244,19 @@ def main():
                    "triangles": ntri, "width": width, "height": height, "rays_per_pixel": rpp, "bounces": depth,
                    "parallelism": "image rows dealt to %d GPU(s) in turn, replicated scene + per-GPU rebuild, gather to rank 0" % world},
         "lbvh_build_ms": round(avg_build_ms, 4),
-        "roofline": {"kernel": "k_traverse_quad", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "roofline": {"kernel": kernel_symbol, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4),
                      "traffic": int(traffic["fetch"] + traffic["write"]) if traffic else None,
-                     "traffic_source": "profiles/r1_c3_final_pmc_summary.txt (FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
-                     "note": "algorithmic bytes are those of the reference's data layout (32 B per box test, 48 B per triangle "
-                             "test); most of them are served by L1/L2, so achieved may exceed the HBM peak - "
-                             "traffic is what actually crossed the memory side",
+                     "traffic_source": traffic["source"] + " (FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
+                     "note": "algorithmic bytes are those of the reference's walk in the reference's data layout (its box and "
+                             "triangle tests per ray, counted exactly, x 32 B and 48 B). k_traverse_quad performs those tests, "
+                             "mostly from L1/L2; k_traverse_spatial returns the same closest hits from a hierarchy of its own "
+                             "with far fewer tests, so achieved exceeds the HBM peak - traffic is what crossed the memory side",
                      "avg_launch_ms": round(avg_trace_s * 1e3, 4), "launches_timed": int(kernel_launches.value),
                      "avg_trace_call_ms": round(avg_trace_call_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                      "rays_per_launch": local_rays, "box_tests_per_ray": round(nodes / max(counted, 1), 2),
                      "triangle_tests_per_ray": round(tris / max(counted, 1), 3), "hit_fraction": round(hits / max(counted, 1), 4)},
-        "build_roofline": {"kernels": "k_morton_packed + 4 x (k_sort_hist, k_sort_scan, k_sort_scatter) + k_leaves + k_upsweep",
+        "build_roofline": {"kernels": "both hierarchies: (k_morton_packed | k_spatial_keys) + 4 x (k_sort_hist, k_sort_scan, k_sort_scatter) + k_leaves + k_upsweep, each",
                            "bound": "hbm", "achieved": round(BUILD_BYTES_PER_TRIANGLE * ntri / (avg_build_ms * 1e-3) / 1e9, 2),
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": round(BUILD_BYTES_PER_TRIANGLE * ntri / (avg_build_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -237,6 +264,8 @@ def main():
         "trace_ms_by_bounce": [round(float(x), 3) for x in np.asarray(trace_ms).reshape(-1, depth).mean(axis=0)],
         "image_mean": round(float(img[..., :3].mean()), 6),
     }
+    if ref_walk:
+        out["reference_order_walk"] = ref_walk
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (scalar OpenMP restatement of the reference shaders) on a bounded sample -

@@ -711,6 +711,7 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
     if (listed) {
         // the rays are the first *listed entries of order: a list another kernel of the same stream has filled
         p.num_rays = *listed;
+        if (p.num_rays == 0u) return;
         const uint32_t deal_block = 1u << p.deal_shift;
         p.queue_chunk = ((((p.num_rays + deal_block - 1u) >> p.deal_shift) + 7u) / 8u) * deal_block;
     }
@@ -1041,8 +1042,13 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                 const bool hit3 = !(tx3 < vmax(tn3, lim)) && (tn3 <= reach);
                 const uint32_t m = (hit0 ? 1u : 0u) | (hit1 ? 2u : 0u) | (hit2 ? 4u : 0u) | (hit3 ? 8u : 0u);
                 if (h < first_leaf_grandparent && m != 0u) {
-                    trail = (trail << 4) | (unsigned long long)(m & (m - 1u));
-                    h = (h << 2) | (uint32_t)__builtin_ctz(m);
+                    // into the nearest of the grandchildren that are hit; the others wait in slot order
+                    const float d0 = hit0 ? tn0 : __builtin_inff(), d1 = hit1 ? tn1 : __builtin_inff();
+                    const float d2 = hit2 ? tn2 : __builtin_inff(), d3 = hit3 ? tn3 : __builtin_inff();
+                    const uint32_t j01 = d1 < d0 ? 1u : 0u, j23 = d3 < d2 ? 3u : 2u;
+                    const uint32_t j = vmin(d2, d3) < vmin(d0, d1) ? j23 : j01;
+                    trail = (trail << 4) | (unsigned long long)(m & ~(1u << j));
+                    h = (h << 2) | j;
                 } else {
                     if (h >= first_leaf_grandparent) {
                         const uint32_t leaf0 = 4u * h - first_leaf;
@@ -1260,7 +1266,10 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     const bool simple_kernel = dev->trace_kernel == RT_TRACE_KERNEL_SIMPLE;
     const bool spatial_kernel = dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL && accel && accel->sp_quads;
     const bool quad_kernel = dev->trace_kernel == RT_TRACE_KERNEL_QUAD || dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL;
-    static const uint32_t leaf_threshold = env_u32("GPURT_LEAF_THRESHOLD", 16u);
+    // (lanes with a leaf waiting that start a triangle round: the walk on the library's own hierarchy meets few
+    // leaves and does better with fuller rounds)
+    static const uint32_t leaf_threshold_env = env_u32("GPURT_LEAF_THRESHOLD", 0u);
+    const uint32_t leaf_threshold = leaf_threshold_env ? leaf_threshold_env : (spatial_kernel ? 24u : 16u);
     static const uint32_t blocks_per_cu = env_u32("GPURT_BLOCKS_PER_CU", 4u);
     static const uint32_t sort_rays = env_u32("GPURT_SORT_RAYS", 1u);
 
@@ -1351,13 +1360,16 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         // walk-length estimate from every fourth pair of nodes at depth 10 (or the deepest level above the leaves of a
         // small tree): deeper, smaller boxes tell long walks from short ones better than all the boxes of depth 8 do
         const uint32_t root_level = p.lv.count - 1u;
-        static const uint32_t probe_depth = env_u32("GPURT_COST_DEPTH", 10u) < 2u ? 2u : env_u32("GPURT_COST_DEPTH", 10u);
+        // (on the library's own hierarchy walks are short and alike: all 32 pairs of depth 6 are enough to order them)
+        const bool on_spatial = spatial_kernel && !stats;
+        static const uint32_t probe_depth_env = env_u32("GPURT_COST_DEPTH", 0u);
+        const uint32_t probe_depth = probe_depth_env >= 2u ? probe_depth_env : (on_spatial ? 6u : 10u);
         const uint32_t depth = root_level > probe_depth ? probe_depth : (root_level > 1u ? root_level - 1u : 1u);
         const uint32_t nodes_there = p.lv.n[root_level - depth];
-        static const uint32_t probe_stride = env_u32("GPURT_COST_STRIDE", 4u) < 1u ? 1u : env_u32("GPURT_COST_STRIDE", 4u);
+        static const uint32_t probe_stride_env = env_u32("GPURT_COST_STRIDE", 0u);
+        const uint32_t probe_stride = probe_stride_env ? probe_stride_env : (on_spatial ? 1u : 4u);
         uint32_t cost_shift = 0u;
         while (((nodes_there / probe_stride) >> cost_shift) > (1u << cost_bits) - 1u) cost_shift++;
-        const bool on_spatial = spatial_kernel && !stats;
         key_nodes = on_spatial ? (const float4*)accel->sp_nodes : nodes;
         key_pairs = on_spatial ? (const float4*)accel->sp_pairs : pairs;
         hipLaunchKernelGGL(k_ray_keys, grid, block, 0, s, nr, ray_in, key_nodes, key_pairs, 1u << (depth - 1u), (nodes_there + 1u) / 2u,
