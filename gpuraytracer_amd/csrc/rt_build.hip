@@ -195,6 +195,55 @@ __global__ __launch_bounds__(256) void k_morton_packed(SceneBounds sb, const flo
 // sorted reference pairs names triangle ci / 3; its key is the interleave of the same ten bits per axis the
 // reference quantises the centroid to (CS_GenerateMortonCodes.hlsl:58-66), without the overlap of the reference's
 // bit spreading.
+// The keys' coordinates are not the reference's equal steps of the scene bounds but steps that hold equal numbers of
+// centroids (per axis): a scene that fills a corner of its bounds - or whose bounds a few far triangles stretch -
+// still uses all 30 bits, and its Morton cells hold similar numbers of triangles, which k_cell_choose needs.
+__device__ __forceinline__ uint32_t axis_step(float c, float mn, float mx) {
+    return (uint32_t)(saturatef((c - mn) / (mx - mn)) * (float)(RT_AXIS_STEPS - 1u));
+}
+__global__ __launch_bounds__(256) void k_axis_hist(SceneBounds sb, const float* __restrict__ dbounds, uint32_t n,
+                                                   const float4* __restrict__ tris, uint32_t* __restrict__ cells) {
+    __shared__ uint32_t s_hist[3u * RT_AXIS_STEPS];
+    for (uint32_t i = threadIdx.x; i < 3u * RT_AXIS_STEPS; i += 256u) s_hist[i] = 0u;
+    __syncthreads();
+    if (dbounds) {
+        sb.mn[0] = dbounds[0]; sb.mn[1] = dbounds[1]; sb.mn[2] = dbounds[2];
+        sb.mx[0] = dbounds[4]; sb.mx[1] = dbounds[5]; sb.mx[2] = dbounds[6];
+    }
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+        const float4 a = tris[3u * t], b = tris[3u * t + 1u], c = tris[3u * t + 2u];
+        const float cx = 0.333333f * ((a.x + b.x) + c.x), cy = 0.333333f * ((a.y + b.y) + c.y), cz = 0.333333f * ((a.z + b.z) + c.z);
+        atomicAdd(&s_hist[axis_step(cx, sb.mn[0], sb.mx[0])], 1u);
+        atomicAdd(&s_hist[RT_AXIS_STEPS + axis_step(cy, sb.mn[1], sb.mx[1])], 1u);
+        atomicAdd(&s_hist[2u * RT_AXIS_STEPS + axis_step(cz, sb.mn[2], sb.mx[2])], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 3u * RT_AXIS_STEPS; i += 256u)
+        if (s_hist[i]) atomicAdd(cells + RT_CELLS_AXIS + i, s_hist[i]);
+}
+// counts -> coordinates: step i of an axis becomes floor(1024 * (centroids in the steps before it) / n); three
+// workgroups (one per axis) of 1024 threads, four steps each
+__global__ __launch_bounds__(1024) void k_axis_map(uint32_t n, uint32_t* __restrict__ cells) {
+    __shared__ uint32_t s_sum[1024];
+    uint32_t* h = cells + RT_CELLS_AXIS + blockIdx.x * RT_AXIS_STEPS;
+    const uint32_t t = threadIdx.x;
+    const uint32_t v0 = h[4u * t], v1 = h[4u * t + 1u], v2 = h[4u * t + 2u], v3 = h[4u * t + 3u];
+    s_sum[t] = v0 + v1 + v2 + v3;
+    __syncthreads();
+    for (uint32_t d = 1u; d < 1024u; d <<= 1) {            // inclusive scan of the per-thread sums
+        const uint32_t add = t >= d ? s_sum[t - d] : 0u;
+        __syncthreads();
+        s_sum[t] += add;
+        __syncthreads();
+    }
+    uint32_t before = s_sum[t] - (v0 + v1 + v2 + v3);
+    const uint32_t c[4] = {v0, v1, v2, v3};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        h[4u * t + j] = min(1023u, (uint32_t)(((unsigned long long)before << 10) / n));
+        before += c[j];
+    }
+}
 __device__ __forceinline__ uint32_t spread_bits3(uint32_t v) {
     v = (v | (v << 16)) & 0x030000ffu;
     v = (v | (v << 8)) & 0x0300f00fu;
@@ -204,7 +253,8 @@ __device__ __forceinline__ uint32_t spread_bits3(uint32_t v) {
 }
 __global__ __launch_bounds__(256) void k_spatial_keys(SceneBounds sb, const float* __restrict__ dbounds, uint32_t n,
                                                       const uint2* __restrict__ sorted, const float4* __restrict__ tris,
-                                                      uint2* __restrict__ keys, uint32_t* __restrict__ ranks) {
+                                                      const uint32_t* __restrict__ cells, uint2* __restrict__ keys,
+                                                      uint32_t* __restrict__ ranks) {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= n) return;
     if (dbounds) {
@@ -214,11 +264,93 @@ __global__ __launch_bounds__(256) void k_spatial_keys(SceneBounds sb, const floa
     const uint32_t ci = sorted[r].y;
     const float4 a = tris[ci], b = tris[ci + 1], c = tris[ci + 2];
     const float cx = 0.333333f * ((a.x + b.x) + c.x), cy = 0.333333f * ((a.y + b.y) + c.y), cz = 0.333333f * ((a.z + b.z) + c.z);
-    const float qx = saturatef((cx - sb.mn[0]) / (sb.mx[0] - sb.mn[0])) * 1023.0f;
-    const float qy = saturatef((cy - sb.mn[1]) / (sb.mx[1] - sb.mn[1])) * 1023.0f;
-    const float qz = saturatef((cz - sb.mn[2]) / (sb.mx[2] - sb.mn[2])) * 1023.0f;
-    keys[r] = make_uint2((spread_bits3((uint32_t)qz) << 2) | (spread_bits3((uint32_t)qy) << 1) | spread_bits3((uint32_t)qx), ci);
+    const uint32_t* map = cells + RT_CELLS_AXIS;
+    const uint32_t qx = map[axis_step(cx, sb.mn[0], sb.mx[0])];
+    const uint32_t qy = map[RT_AXIS_STEPS + axis_step(cy, sb.mn[1], sb.mx[1])];
+    const uint32_t qz = map[2u * RT_AXIS_STEPS + axis_step(cz, sb.mn[2], sb.mx[2])];
+    keys[r] = make_uint2((spread_bits3(qz) << 2) | (spread_bits3(qy) << 1) | spread_bits3(qx), ci);
     ranks[ci / 3u] = r;
+}
+
+// ---- leaf slots of the library's own hierarchy by Morton cell ----
+//
+// A balanced tree over the sorted order has, on every level, nodes whose run of leaves crosses a major boundary
+// of the Morton curve: the run ends in one octant and goes on in the next, and the node's box spans both. Rays meet
+// those boxes on every level. With more leaf slots than leaves (rt_spatial_slots) the leaves of every Morton cell of
+// 2^-T of the curve can start on a slot that is a multiple of slots / 2^T: then every node above that size IS a
+// cell (or half, or a quarter of one), and only inside a cell are leaves laid out by rank. T is the largest of
+// 18, 15, ... 3 whose fullest cell still fits its slots (two triangles per slot); 0 = by rank, as the reference.
+// cells: see RT_CELLS_* in rt_internal.h; all of it is zero before k_cell_hist.
+__global__ __launch_bounds__(256) void k_cell_hist(uint32_t n, const uint2* __restrict__ sorted, uint32_t* __restrict__ cells) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r < n) atomicAdd(cells + RT_CELLS_HIST + (sorted[r].x >> (30u - RT_CELL_BITS_MAX)), 1u);
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    return v;
+}
+// fullest cell at T = 18, 15 and 12, and the counts of the cells of T = 12; one thread per finest cell
+__global__ __launch_bounds__(256) void k_cell_sums(uint32_t* __restrict__ cells) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    uint32_t v = cells[RT_CELLS_HIST + i];
+    const uint32_t m18 = wave_max(v);
+    v += (uint32_t)__shfl_xor((int)v, 1, 64); v += (uint32_t)__shfl_xor((int)v, 2, 64); v += (uint32_t)__shfl_xor((int)v, 4, 64);
+    const uint32_t m15 = wave_max(v);
+    v += (uint32_t)__shfl_xor((int)v, 8, 64); v += (uint32_t)__shfl_xor((int)v, 16, 64); v += (uint32_t)__shfl_xor((int)v, 32, 64);
+    if (lane == 0u) {
+        cells[RT_CELLS_HIST12 + (i >> 6)] = v;
+        atomicMax(cells + 1, m18); atomicMax(cells + 2, m15); atomicMax(cells + 3, v);
+    }
+}
+// fullest cell at T = 9, 6 and 3, and the choice of T; one workgroup of 1024
+__global__ __launch_bounds__(1024) void k_cell_choose(uint32_t* __restrict__ cells, uint32_t slots_log2, uint32_t t_cap) {
+    __shared__ uint32_t s9[512], s6[64], s3[8], s_max[3];
+    const uint32_t t = threadIdx.x;
+    if (t < 3u) s_max[t] = 0u;
+    if (t < 512u) {
+        uint32_t v = 0u;
+        for (uint32_t j = 0; j < 8u; j++) v += cells[RT_CELLS_HIST12 + 8u * t + j];
+        s9[t] = v;
+    }
+    __syncthreads();
+    if (t < 512u) atomicMax(&s_max[0], s9[t]);
+    if (t < 64u) { uint32_t v = 0u; for (uint32_t j = 0; j < 8u; j++) v += s9[8u * t + j]; s6[t] = v; }
+    __syncthreads();
+    if (t < 64u) atomicMax(&s_max[1], s6[t]);
+    if (t < 8u) { uint32_t v = 0u; for (uint32_t j = 0; j < 8u; j++) v += s6[8u * t + j]; s3[t] = v; }
+    __syncthreads();
+    if (t < 8u) atomicMax(&s_max[2], s3[t]);
+    __syncthreads();
+    if (t == 0u) {
+        cells[4] = s_max[0]; cells[5] = s_max[1]; cells[6] = s_max[2];
+        uint32_t chosen = 0u;
+        for (uint32_t k = 0; k < 6u && !chosen; k++) {
+            const uint32_t T = RT_CELL_BITS_MAX - 3u * k;
+            // at least two slots per cell, and room for the fullest cell's triangles in its slots
+            if (T <= t_cap && T + 1u <= slots_log2 && cells[1u + k] <= 2u << (slots_log2 - T)) chosen = T;
+        }
+        cells[0] = chosen;
+    }
+}
+// first rank of every cell at the chosen T (cells without triangles included), and the total behind the last
+__global__ __launch_bounds__(256) void k_cell_starts(uint32_t n, const uint2* __restrict__ sorted, uint32_t* __restrict__ cells) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t T = cells[0], shift = 30u - T;          // codes have 30 bits: T = 0 puts everything into cell 0
+    uint32_t* start = cells + RT_CELLS_START;
+    const uint32_t c = sorted[r].x >> shift;
+    uint32_t from = 0u;                                     // cells from..c start at r
+    bool boundary = true;
+    if (r) {
+        const uint32_t before = sorted[r - 1u].x >> shift;
+        boundary = before != c;
+        from = before + 1u;
+    }
+    if (boundary)
+        for (uint32_t k = from; k <= c; k++) start[k] = r;
+    if (r == n - 1u)
+        for (uint32_t k = c + 1u; k <= (1u << T); k++) start[k] = n;
 }
 
 __global__ __launch_bounds__(256) void k_expand_keys(uint32_t n, const uint2* __restrict__ keys, uint4* __restrict__ morton) {
@@ -596,7 +728,8 @@ template <bool PACKED, bool FUSED>
 __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv, const uint32_t* __restrict__ sorted,
                                                 const uint32_t* __restrict__ indices, const rt_vertex* __restrict__ verts,
                                                 const float4* __restrict__ tris, float4* __restrict__ sorted_tris,
-                                                rt_aabb* __restrict__ nodes, rt_aabb* __restrict__ pairs, float4* __restrict__ quads) {
+                                                rt_aabb* __restrict__ nodes, rt_aabb* __restrict__ pairs, float4* __restrict__ quads,
+                                                const uint32_t* __restrict__ cells, uint32_t slots_log2) {
     __shared__ float s_box[256][6];
     // the workgroup's 256 leaf records are handed over through LDS so that they leave as runs of whole lines
     // (a lane storing its own record writes 16 bytes to each of 64 different lines per instruction: half the rate)
@@ -607,11 +740,31 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
 #pragma unroll
     for (int a = 0; a < 3; a++) { b.mn[a] = 1e30f; b.mx[a] = -1e30f; }
     uint32_t ci0 = 0u, ci1 = 0xffffffffu;
-    if (g < leaves) {
+    // leaf g holds the sorted triangles 2g and 2g + 1; with a cell layout (k_cell_choose) it is slot g, holds the
+    // triangles first + 2j and first + 2j + 1 of its cell, j = its place among the cell's slots, or nothing
+    uint32_t r0 = 2u * g;
+    bool have = g < leaves, two = (2u * g + 1u) < num_prims;
+    if (cells && g < leaves) {
+        const uint32_t wshift = slots_log2 - cells[0];
+        const uint32_t c = g >> wshift, j = g & ((1u << wshift) - 1u);
+        const uint32_t first = cells[RT_CELLS_START + c], count = cells[RT_CELLS_START + c + 1u] - first;
+        r0 = first + 2u * j;
+        have = 2u * j < count;
+        two = 2u * j + 1u < count;
+    }
+    if (g < leaves && !have) {                         // an empty slot: a box no ray enters, a triangle no ray hits
+        if (PACKED) {
+            float corner[6][3];
+#pragma unroll
+            for (int i = 0; i < 6; i++) corner[i][0] = corner[i][1] = corner[i][2] = 0.0f;
+            leaf_triangle_record(s_tri + 5u * threadIdx.x, corner, ci0, ci1);
+        }
+        store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
+    }
+    if (have) {
         constexpr int STRIDE = PACKED ? 2 : 4;
-        ci0 = sorted[(size_t)(2u * g) * STRIDE + 1];
-        const bool two = (2u * g + 1u) < num_prims;
-        if (two) ci1 = sorted[(size_t)(2u * g + 1u) * STRIDE + 1];
+        ci0 = sorted[(size_t)r0 * STRIDE + 1];
+        if (two) ci1 = sorted[(size_t)(r0 + 1u) * STRIDE + 1];
         float corner[6][3];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
@@ -910,7 +1063,8 @@ int rt_bvh_build_leaves(rt_device* dev, const rt_bvh_info* info, const rt_buffer
     lv.count = 0;
     hipLaunchKernelGGL((k_leaves<false, false>), dim3(div_up(leaves, 256u)), dim3(256), 0, dev->stream, n, lv,
                        (const uint32_t*)morton_codes->ptr, (const uint32_t*)indices->ptr, (const rt_vertex*)vertices->ptr,
-                       (const float4*)nullptr, (float4*)nullptr, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, (float4*)nullptr);
+                       (const float4*)nullptr, (float4*)nullptr, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, (float4*)nullptr,
+                       (const uint32_t*)nullptr, 0u);
     return rt_launch_status();
 }
 
@@ -943,7 +1097,7 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
     a->tris = a->sorted_tris = a->quads = a->sp_quads = a->sp_tris = nullptr;
     a->keys_a = a->keys_b = nullptr;
     a->pairs = a->sp_pairs = a->sp_nodes = nullptr;
-    a->ranks = nullptr;
+    a->ranks = a->cells = nullptr;
     const size_t tri_bytes = (size_t)max_primitives * 48u, key_bytes = (size_t)max_primitives * 8u;
     hipError_t e = hipMalloc((void**)&a->tris, tri_bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&a->sorted_tris, ((size_t)max_primitives + 1u) / 2u * RT_LEAF_STRIDE * sizeof(float4));
@@ -955,12 +1109,19 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
         // a smaller scene packed later never needs more slots than the largest one
         if (e == hipSuccess) e = hipMalloc((void**)&a->pairs, (rt_aligned_node_slots(&lv) + 64u) * sizeof(rt_aabb));
         if (e == hipSuccess) e = hipMalloc((void**)&a->quads, rt_quad_records(&lv) * RT_QUAD_STRIDE * sizeof(float4));
-        if (e == hipSuccess) e = hipMalloc((void**)&a->sp_pairs, (rt_aligned_node_slots(&lv) + 64u) * sizeof(rt_aabb));
-        if (e == hipSuccess) e = hipMalloc((void**)&a->sp_quads, rt_quad_records(&lv) * RT_QUAD_STRIDE * sizeof(float4));
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&a->sp_nodes, (size_t)rt_bvh_node_count(max_primitives) * sizeof(rt_aabb));
-    if (e == hipSuccess) e = hipMalloc((void**)&a->sp_tris, ((size_t)max_primitives + 1u) / 2u * RT_LEAF_STRIDE * sizeof(float4));
+    {   // the library's own hierarchy has rt_spatial_slots() leaf slots and all its levels full
+        const uint32_t slots = rt_spatial_slots(max_primitives);
+        rt_levels sl;
+        rt_make_levels(2u * slots, &sl);
+        a->sp_lv = sl;
+        if (e == hipSuccess) e = hipMalloc((void**)&a->sp_pairs, (rt_aligned_node_slots(&sl) + 64u) * sizeof(rt_aabb));
+        if (e == hipSuccess) e = hipMalloc((void**)&a->sp_quads, rt_quad_records(&sl) * RT_QUAD_STRIDE * sizeof(float4));
+        if (e == hipSuccess) e = hipMalloc((void**)&a->sp_nodes, (size_t)rt_bvh_node_count(2u * slots) * sizeof(rt_aabb));
+        if (e == hipSuccess) e = hipMalloc((void**)&a->sp_tris, (size_t)slots * RT_LEAF_STRIDE * sizeof(float4));
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&a->ranks, (size_t)max_primitives * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&a->cells, (size_t)RT_CELLS_WORDS * sizeof(uint32_t));
     if (e != hipSuccess) {
         rt_accel_destroy(a);
         return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
@@ -984,6 +1145,7 @@ int rt_accel_destroy(rt_accel* a) {
     if (a->sp_quads) (void)hipFree(a->sp_quads);
     if (a->sp_tris) (void)hipFree(a->sp_tris);
     if (a->ranks) (void)hipFree(a->ranks);
+    if (a->cells) (void)hipFree(a->cells);
     delete a;
     return RT_OK;
 }
@@ -1101,7 +1263,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     const uint32_t leaves = lv.n[0];
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)src,
                        (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, a->pairs,
-                       a->quads);
+                       a->quads, (const uint32_t*)nullptr, 0u);
     for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
         hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, a->pairs, a->quads);
     if (morton_codes)
@@ -1109,15 +1271,32 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
 
     // the library's own hierarchy: same triangles, same kernels, keys without overlapping bits
     uint2* other = src == a->keys_a ? a->keys_b : a->keys_a;
-    hipLaunchKernelGGL(k_spatial_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, make_bounds(scene_min, scene_max), dbounds, n, src,
-                       a->tris, other, a->ranks);
+    const SceneBounds spb = make_bounds(scene_min, scene_max);
+    RT_HIP(hipMemsetAsync(a->cells + RT_CELLS_AXIS, 0, (size_t)3u * RT_AXIS_STEPS * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_axis_hist, dim3(min(div_up(n, 256u), 512u)), dim3(256), 0, s, spb, dbounds, n, a->tris, a->cells);
+    hipLaunchKernelGGL(k_axis_map, dim3(3), dim3(1024), 0, s, n, a->cells);
+    hipLaunchKernelGGL(k_spatial_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, spb, dbounds, n, src,
+                       a->tris, (const uint32_t*)a->cells, other, a->ranks);
     uint2* sp_src = nullptr;
     rc = rt_sort_pairs(dev, other, src, n, 4u, &sp_src);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)sp_src,
-                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, a->sp_pairs, a->sp_quads);
-    for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
-        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, a->sp_nodes, a->sp_pairs, a->sp_quads);
+    // leaf slots by Morton cell where the cells fit (k_cell_choose), then leaves and levels over all the slots
+    const uint32_t slots = rt_spatial_slots(n);
+    uint32_t slots_log2 = 0u;
+    while ((1u << slots_log2) < slots) slots_log2++;
+    rt_make_levels(2u * slots, &a->sp_lv);
+    const rt_levels& sl = a->sp_lv;
+    RT_HIP(hipMemsetAsync(a->cells, 0, (size_t)RT_CELLS_START * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_cell_hist, dim3(div_up(n, 256u)), dim3(256), 0, s, n, (const uint2*)sp_src, a->cells);
+    hipLaunchKernelGGL(k_cell_sums, dim3((1u << RT_CELL_BITS_MAX) / 256u), dim3(256), 0, s, a->cells);
+    static const uint32_t t_cap = std::getenv("GPURT_CELL_BITS") ? (uint32_t)atoi(std::getenv("GPURT_CELL_BITS")) : RT_CELL_BITS_MAX;
+    hipLaunchKernelGGL(k_cell_choose, dim3(1), dim3(1024), 0, s, a->cells, slots_log2, t_cap);
+    hipLaunchKernelGGL(k_cell_starts, dim3(div_up(n, 256u)), dim3(256), 0, s, n, (const uint2*)sp_src, a->cells);
+    hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(slots, 256u)), dim3(256), 0, s, 2u * slots, sl, (const uint32_t*)sp_src,
+                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, a->sp_pairs, a->sp_quads,
+                       (const uint32_t*)a->cells, slots_log2);
+    for (uint32_t k0 = 8u; k0 + 1u < sl.count; k0 += 8u)
+        hipLaunchKernelGGL(k_upsweep, dim3(div_up(sl.n[k0], 256u)), dim3(256), 0, s, k0, sl, a->sp_nodes, a->sp_pairs, a->sp_quads);
     return rt_launch_status();
 }
 

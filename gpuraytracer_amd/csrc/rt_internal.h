@@ -49,25 +49,6 @@ struct rt_event {
     hipEvent_t ev;
 };
 
-struct rt_accel {
-    rt_device* dev;
-    uint32_t max_prims;
-    uint32_t num_prims;        // set by rt_accel_pack
-    float4* tris;              // [3*max_prims] packed positions, original order
-    float4* sorted_tris;       // [RT_LEAF_STRIDE * leaves] the two triangles of every leaf in Morton order, interleaved
-    float4* quads;             // second private copy of the hierarchy, four grandchildren per 64-byte record (see rt_quad_records)
-    rt_aabb* pairs;            // private copy of the hierarchy as interleaved sibling pairs (rt_levels::aoff placement)
-    uint2* keys_a;             // [max_prims] (code, 3*tri)
-    uint2* keys_b;             // [max_prims]
-    // The library's own hierarchy over the same triangles (same kernels, same shape, codes whose bits do not
-    // overlap), for the traversal that does not follow the reference's order: nodes, sibling pairs, records of
-    // four grandchildren, leaves; and every triangle's place in the reference's order.
-    rt_aabb* sp_nodes;
-    rt_aabb* sp_pairs;
-    float4* sp_quads;
-    float4* sp_tris;
-    uint32_t* ranks;           // [max_prims]
-};
 
 #define RT_HIP(call)                                              \
     do {                                                          \
@@ -139,6 +120,17 @@ static inline bool rt_make_levels(uint32_t num_prims, rt_levels* lv) {
     for (uint32_t j = 0; j < k; j++) lv->aoff[j] = 1u << (k - 1u - j);
     return true;
 }
+// Leaf slots of the library's own hierarchy for a scene of num_prims triangles: a power of two, so that every node
+// covers an aligned run of slots, and twice the leaves where that keeps the byte offsets of the 128-byte leaf
+// records within 32 bits - the room lets whole Morton cells start on aligned slots (see k_cell_choose).
+static inline uint32_t rt_spatial_slots(uint32_t num_prims) {
+    const uint32_t leaves = (num_prims + 1u) / 2u;
+    uint32_t p = 2u;
+    while (p < leaves) p <<= 1;
+    if (p <= (1u << 24)) p <<= 1;
+    return p;
+}
+constexpr uint32_t RT_CELL_BITS_MAX = 18u;     // finest Morton cells leaf slots are aligned to: 2^18
 // A leaf's two triangles take 80 bytes; leaves are laid out one per 128-byte line, because past the L2 a read costs
 // per line touched, not per byte (measured: random 128-byte records are fetched at the rate of 64-byte ones),
 // and an 80-byte stride makes every second leaf straddle two lines.
@@ -154,5 +146,37 @@ static inline bool rt_make_levels(uint32_t num_prims, rt_levels* lv) {
 static inline size_t rt_quad_records(const rt_levels* lv) { return lv->count >= 3u ? (size_t)1u << (lv->count - 2u) : 1u; }
 // 32-byte slots the private copy needs
 static inline size_t rt_aligned_node_slots(const rt_levels* lv) { return (size_t)2u << (lv->count - 1u); }
+
+struct rt_accel {
+    rt_device* dev;
+    uint32_t max_prims;
+    uint32_t num_prims;        // set by rt_accel_pack
+    float4* tris;              // [3*max_prims] packed positions, original order
+    float4* sorted_tris;       // [RT_LEAF_STRIDE * leaves] the two triangles of every leaf in Morton order, interleaved
+    float4* quads;             // second private copy of the hierarchy, four grandchildren per 64-byte record (see rt_quad_records)
+    rt_aabb* pairs;            // private copy of the hierarchy as interleaved sibling pairs (rt_levels::aoff placement)
+    uint2* keys_a;             // [max_prims] (code, 3*tri)
+    uint2* keys_b;             // [max_prims]
+    // The library's own hierarchy over the same triangles (same kernels, same shape, codes whose bits do not
+    // overlap), for the traversal that does not follow the reference's order: nodes, sibling pairs, records of
+    // four grandchildren, leaves; and every triangle's place in the reference's order.
+    rt_aabb* sp_nodes;
+    rt_aabb* sp_pairs;
+    float4* sp_quads;
+    float4* sp_tris;
+    uint32_t* ranks;           // [max_prims]
+    uint32_t* cells;           // Morton-cell bookkeeping of the last build: see the offsets below
+    rt_levels sp_lv;           // shape of that hierarchy at the last build: rt_spatial_slots(num_prims) leaves, all levels full
+};
+// rt_accel::cells, in uint32 (everything before RT_CELLS_START is cleared by every build): [0..7] layout {cell bits T, largest cell at T = 18, 15, ...}; then the triangles per cell
+// of the finest level, the cells of level 12 summed from them, and the first rank of every cell at the chosen level
+constexpr uint32_t RT_CELLS_HIST = 8u;
+constexpr uint32_t RT_CELLS_HIST12 = RT_CELLS_HIST + (1u << RT_CELL_BITS_MAX);
+constexpr uint32_t RT_CELLS_START = RT_CELLS_HIST12 + (1u << 12);
+// ... and, per axis, how many centroids fall into each of 4096 equal steps of the scene bounds, turned into the
+// 10-bit coordinate the keys are made of (k_axis_map)
+constexpr uint32_t RT_AXIS_STEPS = 4096u;
+constexpr uint32_t RT_CELLS_AXIS = RT_CELLS_START + (1u << RT_CELL_BITS_MAX) + 1u;
+constexpr uint32_t RT_CELLS_WORDS = RT_CELLS_AXIS + 3u * RT_AXIS_STEPS;
 
 #endif

@@ -1359,13 +1359,14 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     if (sort_rays) {
         // walk-length estimate from every fourth pair of nodes at depth 10 (or the deepest level above the leaves of a
         // small tree): deeper, smaller boxes tell long walks from short ones better than all the boxes of depth 8 do
-        const uint32_t root_level = p.lv.count - 1u;
         // (on the library's own hierarchy walks are short and alike: all 32 pairs of depth 6 are enough to order them)
         const bool on_spatial = spatial_kernel && !stats;
+        const rt_levels& kl = on_spatial ? accel->sp_lv : p.lv;
+        const uint32_t root_level = kl.count - 1u;
         static const uint32_t probe_depth_env = env_u32("GPURT_COST_DEPTH", 0u);
         const uint32_t probe_depth = probe_depth_env >= 2u ? probe_depth_env : (on_spatial ? 6u : 10u);
         const uint32_t depth = root_level > probe_depth ? probe_depth : (root_level > 1u ? root_level - 1u : 1u);
-        const uint32_t nodes_there = p.lv.n[root_level - depth];
+        const uint32_t nodes_there = kl.n[root_level - depth];
         static const uint32_t probe_stride_env = env_u32("GPURT_COST_STRIDE", 0u);
         const uint32_t probe_stride = probe_stride_env ? probe_stride_env : (on_spatial ? 1u : 4u);
         uint32_t cost_shift = 0u;
@@ -1400,10 +1401,12 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     // k_traverse_quad addresses its records and the leaves with 32-bit byte offsets
     const bool offsets_fit = rt_aligned_node_slots(&p.lv) * sizeof(rt_aabb) <= 0xffffffffull && (size_t)p.lv.n[0] * 128u <= 0xffffffffull;
     if (stats) RT_LAUNCH_TRAVERSE(true);
-    else if (spatial_kernel && offsets_fit && p.lv.count >= 3u) {
+    else if (spatial_kernel && offsets_fit && p.lv.count >= 3u && (size_t)accel->sp_lv.n[0] * 128u <= 0xffffffffull) {
         // first the walk on the library's own hierarchy, then the reference's walk for the rays it has listed
         uint32_t* listed = dev->queue_counter + 128;
-        hipLaunchKernelGGL(k_traverse_spatial, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in,
+        TraceParams ps = p;
+        ps.lv = accel->sp_lv;
+        hipLaunchKernelGGL(k_traverse_spatial, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, ps, ray_in,
                            (const float4*)accel->sp_nodes, (const float4*)accel->sp_pairs, (const float4*)accel->sp_quads,
                            (const float4*)accel->sp_tris, dev->hit_records, dev->hit_ci, dev->queue_counter, order, st,
                            (const uint32_t*)accel->ranks, dev->listed_rays, listed);
