@@ -196,17 +196,23 @@ def main():
             pipe.render(depth)
             torch.cuda.synchronize()
             dev.lib.rt_device_set_traverse_timing(dev.handle, 1)
+            ref_build_events = []
+            pipe.build = timed(raw_build, ref_build_events)      # builds the reference's hierarchy alone
+            timing["on"] = True
             t1 = time.perf_counter()
             for _ in range(2):
                 step()
             torch.cuda.synchronize()
             ref_elapsed = time.perf_counter() - t1
+            timing["on"] = False
+            pipe.build = timed(raw_build, build_events)
             rk_ms, rk_n = ctypes.c_double(0.0), ctypes.c_uint32(0)
             dev.lib.rt_device_traverse_timing(dev.handle, ctypes.byref(rk_ms), ctypes.byref(rk_n))
             dev.lib.rt_device_set_traverse_timing(dev.handle, 0)
             dev.lib.rt_device_set_trace_kernel(dev.handle, 3)        # RT_TRACE_KERNEL_SPATIAL
             ref_walk = {"kernel": "k_traverse_quad", "value": round(width * height * rpp * depth * 2 / ref_elapsed / 1e6, 3),
-                        "unit": "Mrays/s", "steps": 2, "avg_launch_ms": round(rk_ms.value / max(rk_n.value, 1), 4)}
+                        "unit": "Mrays/s", "steps": 2, "avg_launch_ms": round(rk_ms.value / max(rk_n.value, 1), 4),
+                        "lbvh_build_ms": round(float(np.mean([a.elapsed_ms(b) for a, b in ref_build_events])), 4)}
 
         # exact traversal counters of one more frame (untimed, instrumented kernel variant)
         stats_buf = dev.alloc(32)

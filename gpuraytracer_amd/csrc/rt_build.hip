@@ -300,7 +300,10 @@ __global__ __launch_bounds__(256) void k_cell_sums(uint32_t* __restrict__ cells)
     v += (uint32_t)__shfl_xor((int)v, 8, 64); v += (uint32_t)__shfl_xor((int)v, 16, 64); v += (uint32_t)__shfl_xor((int)v, 32, 64);
     if (lane == 0u) {
         cells[RT_CELLS_HIST12 + (i >> 6)] = v;
-        atomicMax(cells + 1, m18); atomicMax(cells + 2, m15); atomicMax(cells + 3, v);
+        // (a plain read first: most waves find a larger maximum already there and skip the contended atomic)
+        if (m18 > cells[1]) atomicMax(cells + 1, m18);
+        if (m15 > cells[2]) atomicMax(cells + 2, m15);
+        if (v > cells[3]) atomicMax(cells + 3, v);
     }
 }
 // fullest cell at T = 9, 6 and 3, and the choice of T; one workgroup of 1024
@@ -1098,6 +1101,7 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
     a->keys_a = a->keys_b = nullptr;
     a->pairs = a->sp_pairs = a->sp_nodes = nullptr;
     a->ranks = a->cells = nullptr;
+    a->sp_built = false;
     const size_t tri_bytes = (size_t)max_primitives * 48u, key_bytes = (size_t)max_primitives * 8u;
     hipError_t e = hipMalloc((void**)&a->tris, tri_bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&a->sorted_tris, ((size_t)max_primitives + 1u) / 2u * RT_LEAF_STRIDE * sizeof(float4));
@@ -1269,7 +1273,10 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     if (morton_codes)
         hipLaunchKernelGGL(k_expand_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, n, src, (uint4*)morton_codes->ptr);
 
-    // the library's own hierarchy: same triangles, same kernels, keys without overlapping bits
+    // the library's own hierarchy: same triangles, same kernels, keys without overlapping bits. Only the traversal
+    // kernel that walks it needs it.
+    a->sp_built = dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL;
+    if (!a->sp_built) return rt_launch_status();
     uint2* other = src == a->keys_a ? a->keys_b : a->keys_a;
     const SceneBounds spb = make_bounds(scene_min, scene_max);
     RT_HIP(hipMemsetAsync(a->cells + RT_CELLS_AXIS, 0, (size_t)3u * RT_AXIS_STEPS * sizeof(uint32_t), s));

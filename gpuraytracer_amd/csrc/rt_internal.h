@@ -166,6 +166,7 @@ struct rt_accel {
     float4* sp_tris;
     uint32_t* ranks;           // [max_prims]
     uint32_t* cells;           // Morton-cell bookkeeping of the last build: see the offsets below
+    bool sp_built;             // the last build made it (builds on a device set to another traversal kernel do not)
     rt_levels sp_lv;           // shape of that hierarchy at the last build: rt_spatial_slots(num_prims) leaves, all levels full
 };
 // rt_accel::cells, in uint32 (everything before RT_CELLS_START is cleared by every build): [0..7] layout {cell bits T, largest cell at T = 18, 15, ...}; then the triangles per cell

@@ -1264,12 +1264,12 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
 
     // the traversal kernel is a device setting (rt_device_set_trace_kernel); the other knobs are read once
     const bool simple_kernel = dev->trace_kernel == RT_TRACE_KERNEL_SIMPLE;
-    const bool spatial_kernel = dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL && accel && accel->sp_quads;
+    const bool spatial_kernel = dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL && accel && accel->sp_built;
     const bool quad_kernel = dev->trace_kernel == RT_TRACE_KERNEL_QUAD || dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL;
     // (lanes with a leaf waiting that start a triangle round: the walk on the library's own hierarchy meets few
     // leaves and does better with fuller rounds)
     static const uint32_t leaf_threshold_env = env_u32("GPURT_LEAF_THRESHOLD", 0u);
-    const uint32_t leaf_threshold = leaf_threshold_env ? leaf_threshold_env : (spatial_kernel ? 24u : 16u);
+    const uint32_t leaf_threshold = leaf_threshold_env ? leaf_threshold_env : (spatial_kernel ? 32u : 16u);
     static const uint32_t blocks_per_cu = env_u32("GPURT_BLOCKS_PER_CU", 4u);
     static const uint32_t sort_rays = env_u32("GPURT_SORT_RAYS", 1u);
 

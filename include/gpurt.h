@@ -92,7 +92,9 @@ int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats);
  * second hierarchy that rt_accel_build makes from non-overlapping Morton codes, several times faster; rays for which
  * the reference's order could decide are walked again by QUAD. It differs from the reference only where a triangle's
  * computed hit distance is closer than the entry of every box around it by more than the closest hit found - see
- * the kernel's description; no test scene has such a ray. The environment variable
+ * the kernel's description; no test scene has such a ray. rt_accel_build makes the second hierarchy only while the
+ * device is set to SPATIAL; an accel built under another setting is traced by QUAD until it is built again. The
+ * environment variable
  * GPURT_TRACE_KERNEL = spatial | quad | wave | simple sets the initial choice of a new device. */
 #define RT_TRACE_KERNEL_QUAD 0
 #define RT_TRACE_KERNEL_WAVE 1
