@@ -299,18 +299,30 @@ __global__ __launch_bounds__(256) void k_cell_sums(uint32_t* __restrict__ cells)
     const uint32_t m15 = wave_max(v);
     v += (uint32_t)__shfl_xor((int)v, 8, 64); v += (uint32_t)__shfl_xor((int)v, 16, 64); v += (uint32_t)__shfl_xor((int)v, 32, 64);
     if (lane == 0u) {
+        // the wave's maxima go to the (still unused) table of cell starts; k_cell_choose gathers them: thousands of
+        // atomics on three words would take longer than the rest of the build's bookkeeping together
         cells[RT_CELLS_HIST12 + (i >> 6)] = v;
-        // (a plain read first: most waves find a larger maximum already there and skip the contended atomic)
-        if (m18 > cells[1]) atomicMax(cells + 1, m18);
-        if (m15 > cells[2]) atomicMax(cells + 2, m15);
-        if (v > cells[3]) atomicMax(cells + 3, v);
+        cells[RT_CELLS_START + (i >> 6)] = m18;
+        cells[RT_CELLS_START + 4096u + (i >> 6)] = m15;
     }
 }
 // fullest cell at T = 9, 6 and 3, and the choice of T; one workgroup of 1024
 __global__ __launch_bounds__(1024) void k_cell_choose(uint32_t* __restrict__ cells, uint32_t slots_log2, uint32_t t_cap) {
     __shared__ uint32_t s9[512], s6[64], s3[8], s_max[3];
     const uint32_t t = threadIdx.x;
-    if (t < 3u) s_max[t] = 0u;
+    __shared__ uint32_t s_fine[3];
+    if (t < 3u) { s_max[t] = 0u; s_fine[t] = 0u; }
+    __syncthreads();
+    {   // fullest cells of T = 18, 15, 12 from the per-wave values of k_cell_sums
+        uint32_t m18 = 0u, m15 = 0u, m12 = 0u;
+        for (uint32_t j = t; j < 4096u; j += 1024u) {
+            m18 = max(m18, cells[RT_CELLS_START + j]);
+            m15 = max(m15, cells[RT_CELLS_START + 4096u + j]);
+            m12 = max(m12, cells[RT_CELLS_HIST12 + j]);
+        }
+        m18 = wave_max(m18); m15 = wave_max(m15); m12 = wave_max(m12);
+        if ((t & 63u) == 0u) { atomicMax(&s_fine[0], m18); atomicMax(&s_fine[1], m15); atomicMax(&s_fine[2], m12); }
+    }
     if (t < 512u) {
         uint32_t v = 0u;
         for (uint32_t j = 0; j < 8u; j++) v += cells[RT_CELLS_HIST12 + 8u * t + j];
@@ -326,6 +338,7 @@ __global__ __launch_bounds__(1024) void k_cell_choose(uint32_t* __restrict__ cel
     if (t < 8u) atomicMax(&s_max[2], s3[t]);
     __syncthreads();
     if (t == 0u) {
+        cells[1] = s_fine[0]; cells[2] = s_fine[1]; cells[3] = s_fine[2];
         cells[4] = s_max[0]; cells[5] = s_max[1]; cells[6] = s_max[2];
         uint32_t chosen = 0u;
         for (uint32_t k = 0; k < 6u && !chosen; k++) {
