@@ -745,8 +745,11 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
                                                 const uint32_t* __restrict__ indices, const rt_vertex* __restrict__ verts,
                                                 const float4* __restrict__ tris, float4* __restrict__ sorted_tris,
                                                 rt_aabb* __restrict__ nodes, rt_aabb* __restrict__ pairs, float4* __restrict__ quads,
-                                                const uint32_t* __restrict__ cells, uint32_t slots_log2) {
+                                                const uint32_t* __restrict__ cells, uint32_t slots_log2,
+                                                const uint32_t* __restrict__ ranks) {
     __shared__ float s_box[256][6];
+    // with ranks: the sixth 16 bytes of a leaf record hold the places of its two triangles in the reference's order
+    __shared__ uint2 s_rank[PACKED ? 256 : 1];
     // the workgroup's 256 leaf records are handed over through LDS so that they leave as runs of whole lines
     // (a lane storing its own record writes 16 bytes to each of 64 different lines per instruction: half the rate)
     __shared__ float4 s_tri[PACKED ? 256 * 5 : 1];
@@ -805,6 +808,7 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
         store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
     }
     if (PACKED) {
+        s_rank[threadIdx.x] = (ranks && have) ? make_uint2(ranks[ci0 / 3u], two ? ranks[ci1 / 3u] : 0xffffffffu) : make_uint2(0u, 0u);
         __syncthreads();
         const uint32_t first = blockIdx.x * 256u;
 #pragma unroll
@@ -812,7 +816,10 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
             const uint32_t e = i * 256u + threadIdx.x;             // float4 e of the workgroup's 256 x 128 bytes
             const uint32_t leaf = e >> 3, j = e & 7u;
             if (first + leaf < leaves)
-                sorted_tris[RT_LEAF_STRIDE * (size_t)first + e] = j < 5u ? s_tri[5u * leaf + j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                sorted_tris[RT_LEAF_STRIDE * (size_t)first + e] =
+                    j < 5u ? s_tri[5u * leaf + j]
+                           : (j == 5u ? make_float4(__uint_as_float(s_rank[leaf].x), __uint_as_float(s_rank[leaf].y), 0.0f, 0.0f)
+                                      : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         }
     }
     if (PACKED && pairs) {                             // same for the whole grid
@@ -1080,7 +1087,7 @@ int rt_bvh_build_leaves(rt_device* dev, const rt_bvh_info* info, const rt_buffer
     hipLaunchKernelGGL((k_leaves<false, false>), dim3(div_up(leaves, 256u)), dim3(256), 0, dev->stream, n, lv,
                        (const uint32_t*)morton_codes->ptr, (const uint32_t*)indices->ptr, (const rt_vertex*)vertices->ptr,
                        (const float4*)nullptr, (float4*)nullptr, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, (float4*)nullptr,
-                       (const uint32_t*)nullptr, 0u);
+                       (const uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
     return rt_launch_status();
 }
 
@@ -1280,7 +1287,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     const uint32_t leaves = lv.n[0];
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)src,
                        (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, a->pairs,
-                       a->quads, (const uint32_t*)nullptr, 0u);
+                       a->quads, (const uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
     for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
         hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, a->pairs, a->quads);
     if (morton_codes)
@@ -1314,7 +1321,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     hipLaunchKernelGGL(k_cell_starts, dim3(div_up(n, 256u)), dim3(256), 0, s, n, (const uint2*)sp_src, a->cells);
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(slots, 256u)), dim3(256), 0, s, 2u * slots, sl, (const uint32_t*)sp_src,
                        (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, a->sp_pairs, a->sp_quads,
-                       (const uint32_t*)a->cells, slots_log2);
+                       (const uint32_t*)a->cells, slots_log2, (const uint32_t*)a->ranks);
     for (uint32_t k0 = 8u; k0 + 1u < sl.count; k0 += 8u)
         hipLaunchKernelGGL(k_upsweep, dim3(div_up(sl.n[k0], 256u)), dim3(256), 0, s, k0, sl, a->sp_nodes, a->sp_pairs, a->sp_quads);
     return rt_launch_status();

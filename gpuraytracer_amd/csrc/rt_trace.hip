@@ -956,7 +956,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
         //    A refill stalls the whole wave for an atomic and two dependent loads, so it waits until several lanes are
         //    free, unless nobody could walk meanwhile.
         const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(w == kIdle);
-        if (need_mask && ((uint32_t)__popcll(need_mask) >= p.refill_threshold || !__builtin_amdgcn_ballot_w64(w <= kFifo - 4u))) {
+        if (need_mask && ((uint32_t)__popcll(need_mask) >= p.refill_threshold || !__builtin_amdgcn_ballot_w64(w <= kFifo - 1u))) {
             if (queues_tried >= 8u) {
                 if (w == kIdle) w = kDry;
             } else {
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
         // 2. walk until a triangle round is due, a lane has finished its ray, or nobody can walk
         unsigned long long waiting_mask, walking_mask;
         for (;;) {
-            if (w <= kFifo - 4u) {
+            if (w <= kFifo - 1u) {
                 const uint4* rec = reinterpret_cast<const uint4*>(quad_bytes + (h << 6));
                 const uint4 u0 = rec[0], u1 = rec[1], u2 = rec[2];
                 const v2f ix = {inv_w.x, inv_w.x}, iy = {inv_w.y, inv_w.y}, iz = {inv_w.z, inv_w.z};
@@ -1050,12 +1050,14 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                     trail = (trail << 4) | (unsigned long long)(m & ~(1u << j));
                     h = (h << 2) | j;
                 } else {
-                    if (h >= first_leaf_grandparent) {
-                        const uint32_t leaf0 = 4u * h - first_leaf;
-                        if (hit0) { s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0, __float_as_uint(tn0)); w++; }
-                        if (hit1) { s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0 + 1u, __float_as_uint(tn1)); w++; }
-                        if (hit2) { s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0 + 2u, __float_as_uint(tn2)); w++; }
-                        if (hit3) { s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] = make_uint2(leaf0 + 3u, __float_as_uint(tn3)); w++; }
+                    if (h >= first_leaf_grandparent && m != 0u) {
+                        // one entry for the up to four leaves that are hit: first leaf, which of the four (bits 28 - 31:
+                        // leaf numbers stay below 2^25), and the smallest of their entry distances
+                        const float d0 = hit0 ? tn0 : __builtin_inff(), d1 = hit1 ? tn1 : __builtin_inff();
+                        const float d2 = hit2 ? tn2 : __builtin_inff(), d3 = hit3 ? tn3 : __builtin_inff();
+                        s_fifo[((wait_head + w) & (kFifo - 1u)) * 256u] =
+                            make_uint2((4u * h - first_leaf) | (m << 28), __float_as_uint(vmin(vmin(d0, d1), vmin(d2, d3))));
+                        w++;
                     }
                     // back to the first noted node of the nearest level that has one, or the walk is over
                     if (trail == 0ull) {
@@ -1071,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                 }
             }
             waiting_mask = __builtin_amdgcn_ballot_w64((w & 15u) != 0u);
-            walking_mask = __builtin_amdgcn_ballot_w64(w <= kFifo - 4u);
+            walking_mask = __builtin_amdgcn_ballot_w64(w <= kFifo - 1u);
             if (!walking_mask || (uint32_t)__popcll(waiting_mask) >= p.leaf_threshold) break;
             if ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(w >= kOver && w != kDry)) >= p.refill_threshold) break;
         }
@@ -1079,12 +1081,21 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
         // 3. triangle round once enough lanes have a leaf waiting (or nobody can walk any more)
         if (waiting_mask && ((uint32_t)__popcll(waiting_mask) >= p.leaf_threshold || !walking_mask)) {
             if ((w & 15u) != 0u) {
+                // the oldest entry's next leaf; the entry goes when its last leaf is taken or its leaves lie beyond reach
                 const uint2 e = s_fifo[wait_head * 256u];
-                wait_head = (wait_head + 1u) & (kFifo - 1u);
-                w--;
-                if (__uint_as_float(e.y) <= reach) {
-                    const float4* t = reinterpret_cast<const float4*>(leaf_bytes + e.x * 128u);
+                const bool in_reach = __uint_as_float(e.y) <= reach;
+                const uint32_t left = e.x >> 28, leaf = (e.x & 0x0fffffffu) + (uint32_t)__builtin_ctz(left);
+                const uint32_t rest = left & (left - 1u);
+                if (rest != 0u && in_reach) {
+                    s_fifo[wait_head * 256u].x = (e.x & 0x0fffffffu) | (rest << 28);
+                } else {
+                    wait_head = (wait_head + 1u) & (kFifo - 1u);
+                    w--;
+                }
+                if (in_reach) {
+                    const float4* t = reinterpret_cast<const float4*>(leaf_bytes + leaf * 128u);
                     const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
+                    const float2 places = *reinterpret_cast<const float2*>(t + 5);      // of the two triangles in the reference's order
                     const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
                     Hit h0, h1;
                     intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
@@ -1098,7 +1109,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                             if ((k ? may1 : may0) && hk.t <= reach) {
                                 // The reference tests this triangle only if the box of ITS leaf of the triangle lets
                                 // the ray in: that leaf is the pair of neighbours in the reference's order.
-                                const uint32_t rank = ranks[ck / 3u];
+                                const uint32_t rank = __float_as_uint(k ? places.y : places.x);
                                 const float4* rt = reinterpret_cast<const float4*>(ref_leaf_bytes + (rank >> 1) * 128u);
                                 const float entry = leaf_box_entry(org, inv_d, lim, rt[0], rt[1], rt[2], rt[3], rt[4]);
                                 if (entry < __builtin_inff()) {
