@@ -321,6 +321,60 @@ def test_equal_distances_and_flat_boxes_follow_the_reference_order(device, oracl
     assert g[8]["rays_hit"] > 0
 
 
+def _clumped_scene(kind, n, seed=11):
+    """Scenes whose centroids fill their bounds unevenly, for the second hierarchy's key coordinates and cell layout:
+    'clusters' = two tight clusters far apart plus a few triangles far out, 'diagonal' = centroids along a line,
+    'stacked' = every triangle around the same point, 'slab' = a flat sheet (no extent on one axis of the centroids)."""
+    from gpuraytracer_amd import scenes
+    from gpuraytracer_amd.capi import vertex_dtype
+    rng = np.random.RandomState(seed)
+    if kind == "clusters":
+        c = np.where(rng.uniform(size=(n, 1)) < 0.5, -0.8, 0.8) + rng.normal(0, 0.05, (n, 3))
+        c[:5] = rng.uniform(-30, 30, (5, 3))
+        size = 0.05
+    elif kind == "diagonal":
+        t = rng.uniform(-1, 1, (n, 1))
+        c = np.repeat(t, 3, axis=1) * np.array([1.0, 0.7, 0.4])
+        size = 0.08
+    elif kind == "stacked":
+        c = np.zeros((n, 3)) + np.array([0.1, -0.2, 0.3])
+        size = 0.6
+    else:
+        c = rng.uniform(-1, 1, (n, 3))
+        c[:, 2] = 0.5
+        size = 0.1
+    c = c.astype(np.float32).reshape(n, 1, 3)
+    off = rng.uniform(-size, size, (n, 3, 3)).astype(np.float32)
+    if kind in ("stacked", "slab"):
+        off -= off.mean(axis=1, keepdims=True)          # every centroid (nearly) at the same point / in the same plane
+        if kind == "slab":
+            off[:, :, 2] = 0.0
+    v = np.zeros(3 * n, dtype=vertex_dtype)
+    v["position"] = (c + off).reshape(-1, 3)
+    v["normal"] = (0, 0, -1)
+    v["uv"] = rng.uniform(0, 1, (3 * n, 2)).astype(np.float32)
+    v["material_id"] = np.repeat(np.arange(n) % 8, 3)
+    idx = np.arange(3 * n, dtype=np.uint32)
+    atlas, ids = scenes.default_atlas()
+    smin, smax = scenes.centroid_bounds(v, idx)
+    cam = dict(position=(0.0, 0.0, -3.0), focus=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=1.2, near_z=0.01, far_z=10000.0)
+    return dict(vertices=v, indices=idx, materials=scenes.synthetic_materials(), texture_ids=ids, atlas=atlas, scene_min=smin,
+                scene_max=smax, camera=cam, name="%s-%d" % (kind, n))
+
+
+@pytest.mark.parametrize("kind,n", [("clusters", 6000), ("diagonal", 6000), ("stacked", 700), ("slab", 5000), ("clusters", 300000)])
+def test_unevenly_filled_scenes_trace_exactly(device, oracle, kind, n):
+    """The second hierarchy lays its leaves out by Morton cell where the cells' populations allow it and by rank where
+    they do not, on coordinates derived from the centroids' distribution: clusters, lines, a single point and a flat
+    sheet must give the oracle's buffers like any other scene."""
+    sc = _clumped_scene(kind, n)
+    w, h = (96, 54) if n <= 10000 else (64, 36)
+    g = _render_both(device, oracle, sc, w, h, 4, depth=2, kernel=KERNEL_SPATIAL)
+    for name, a, b in (("tone-mapped", g[0], g[1]), ("result", g[2], g[3]), ("emitted", g[4], g[5]), ("rays", g[6], g[7])):
+        assert a.view(np.uint32).tobytes() == b.view(np.uint32).tobytes(), "%s differs for %s" % (name, sc["name"])
+    assert g[8]["rays_hit"] > 0, "some ray must hit"
+
+
 def test_invalid_trace_kernel_is_rejected(device):
     from gpuraytracer_amd import capi
     assert device.lib.rt_device_set_trace_kernel(device.handle, 4) == capi.RT_ERR_INVALID_ARGUMENT
