@@ -117,7 +117,7 @@ def main():
     cam = scene["camera"]
     iv, ip = host_py.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], width / height, cam["near_z"],
                                      cam["far_z"])
-    total_frames = args.steps + args.warmup + 6      # + the counting frame and the frames of the walk in the reference's order
+    total_frames = args.steps + args.warmup + 7      # + the counting frame and the frames of the walk in the reference's order
     rs = iter(scenes.mt19937_raw(1, 3 * total_frames).reshape(-1, 3))
     ts = iter(scenes.mt19937_raw(2, 3 * total_frames * depth).reshape(-1, 3))
 
@@ -214,6 +214,17 @@ def main():
                         "unit": "Mrays/s", "steps": 2, "avg_launch_ms": round(rk_ms.value / max(rk_n.value, 1), 4),
                         "lbvh_build_ms": round(float(np.mean([a.elapsed_ms(b) for a, b in ref_build_events])), 4)}
 
+        # counters of the walk on the library's own hierarchy (one more frame, untimed): its own algorithmic bytes
+        walk = None
+        if kernel_name == "spatial":
+            walk_buf = dev.alloc(32)
+            dev.lib.rt_device_set_walk_stats(dev.handle, walk_buf.handle)
+            pipe.render(depth)
+            dev.sync()
+            dev.lib.rt_device_set_walk_stats(dev.handle, None)
+            walk = [int(x) for x in walk_buf.download(np.uint64, 4)]
+            walk_buf.free()
+
         # exact traversal counters of one more frame (untimed, instrumented kernel variant)
         stats_buf = dev.alloc(32)
         dev.lib.rt_device_set_trace_stats(dev.handle, stats_buf.handle)
@@ -272,6 +283,17 @@ def main():
     }
     if ref_walk:
         out["reference_order_walk"] = ref_walk
+    if walk:
+        # what k_traverse_spatial itself reads and writes per launch in its own layout: 32 B ray + 8 B order entry in,
+        # 20 B hit record out, 48 B of a 64-byte record per step, 88 B of a leaf record per leaf tested
+        launches = depth
+        own_bytes = (local_rays * launches * 60 + walk[0] * 48 + walk[2] * 88) / launches
+        out["roofline"]["own_layout"] = {
+            "steps_per_ray": round(walk[0] / (local_rays * launches), 2), "empty_steps_per_ray": round(walk[1] / (local_rays * launches), 2),
+            "leaves_per_ray": round(walk[2] / (local_rays * launches), 2), "bytes_per_launch": int(own_bytes),
+            "achieved": round(own_bytes / avg_trace_s / 1e9, 2), "unit": "GB/s", "frac": round(own_bytes / avg_trace_s / 1e9 / HBM_PEAK_GBPS, 4),
+            "note": "bytes the kernel requests in its own data layout (mostly L1/L2 hits); the kernel is bound by vector "
+                    "instructions and divergence, see DESIGN.md section 5"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (scalar OpenMP restatement of the reference shaders) on a bounded sample -

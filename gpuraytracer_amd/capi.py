@@ -122,6 +122,7 @@ SIGNATURES = {
     "rt_accel_build": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
     "rt_device_set_trace_kernel": (C.c_int, [_P, C.c_int]),
     "rt_device_listed_rays": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    "rt_device_set_walk_stats": (C.c_int, [_P, _P]),
     "rt_scene_bounds": (C.c_int, [_P, _U32, _P, _P, _P]),
     "rt_accel_pack_bounds": (C.c_int, [_P, _U32, _P, _P, _P]),
     "rt_accel_build_device_bounds": (C.c_int, [_P, _P, _P, _P]),

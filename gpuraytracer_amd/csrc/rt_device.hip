@@ -34,6 +34,7 @@ int rt_device_create(int gpu_index, rt_device** out) {
     d->ray_keys_a = nullptr;
     d->ray_keys_b = nullptr;
     d->listed_rays = nullptr;
+    d->walk_stats = nullptr;
     d->conv_pairs = nullptr;
     d->conv_tris = nullptr;
     d->conv_quads = nullptr;

@@ -16,6 +16,7 @@ struct rt_device {
     size_t sort_table_words;
     uint32_t* sort_totals;     // [256] digit totals + [256] exclusive digit bases
     unsigned long long* trace_stats;   // optional traversal counters (rt_device_set_trace_stats)
+    unsigned long long* walk_stats;    // optional counters of the walk on the library's own hierarchy (rt_device_set_walk_stats)
     // workspace of the wavefront trace: closest-hit records between the traversal and shading kernels
     float4* hit_records;       // [hit_capacity] (t, u, v, facing)
     uint32_t* hit_ci;          // [hit_capacity] first index slot of the hit triangle

@@ -913,13 +913,14 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
 //    listed rays again on the reference's hierarchy.
 // What stays out of reach of this argument is a triangle whose computed hit distance is closer than the closest hit
 // kept here although its boxes are entered beyond it: the reference may keep such a hit, this kernel never sees it.
+template <bool COUNT>
 __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const float4* __restrict__ rays, const float4* __restrict__ nodes,
                                                        const float4* __restrict__ pairs, const float4* __restrict__ quads,
                                                        const float4* __restrict__ sorted_tris, float4* __restrict__ hit_records,
                                                        uint32_t* __restrict__ hit_ci, uint32_t* __restrict__ queue,
                                                        const uint2* __restrict__ order, const float4* __restrict__ ref_tris,
                                                        const uint32_t* __restrict__ ranks, uint2* __restrict__ flagged,
-                                                       uint32_t* __restrict__ flag_count) {
+                                                       uint32_t* __restrict__ flag_count, unsigned long long* __restrict__ walk_stats) {
     extern __shared__ uint32_t s_dyn[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t root_level = p.lv.count - 1u;               // >= 2
@@ -951,6 +952,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
     unsigned long long trail = 0ull;
     uint32_t wait_head = 0u;
     uint32_t q = blockIdx.x & 7u, queues_tried = 0u;       // wave-uniform
+    uint32_t n_steps = 0u, n_empty = 0u, n_leaves = 0u;    // COUNT: this wave's steps, steps that hit nothing, leaves tested
 
     for (;;) {
         // 1. refill: every lane without a ray takes the next index; one atomic per wave (see k_traverse)
@@ -1014,7 +1016,14 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
             }
         }
         if (!__builtin_amdgcn_ballot_w64(w < kIdle)) {
-            if (!__builtin_amdgcn_ballot_w64(w != kDry)) break;       // queues empty and nothing in flight: the wave is done
+            if (!__builtin_amdgcn_ballot_w64(w != kDry)) {            // queues empty and nothing in flight: the wave is done
+                if (COUNT && lane == 0u) {
+                    atomicAdd(walk_stats, (unsigned long long)n_steps);
+                    atomicAdd(walk_stats + 1, (unsigned long long)n_empty);
+                    atomicAdd(walk_stats + 2, (unsigned long long)n_leaves);
+                }
+                break;
+            }
             continue;
         }
 
@@ -1042,6 +1051,10 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                 const bool hit2 = !(tx2 < vmax(tn2, lim)) && (tn2 <= reach);
                 const bool hit3 = !(tx3 < vmax(tn3, lim)) && (tn3 <= reach);
                 const uint32_t m = (hit0 ? 1u : 0u) | (hit1 ? 2u : 0u) | (hit2 ? 4u : 0u) | (hit3 ? 8u : 0u);
+                if (COUNT) {
+                    n_steps += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(true));
+                    n_empty += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(m == 0u));
+                }
                 if (h < first_leaf_grandparent && m != 0u) {
                     // into the nearest of the grandchildren that are hit; the others wait in slot order
                     const float d0 = hit0 ? tn0 : __builtin_inff(), d1 = hit1 ? tn1 : __builtin_inff();
@@ -1094,6 +1107,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                     w--;
                 }
                 if (in_reach) {
+                    if (COUNT) n_leaves += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(true));
                     const float4* t = reinterpret_cast<const float4*>(leaf_bytes + leaf * 128u);
                     const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
                     const float2 places = *reinterpret_cast<const float2*>(t + 5);      // of the two triangles in the reference's order
@@ -1418,10 +1432,14 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         uint32_t* listed = dev->queue_counter + 128;
         TraceParams ps = p;
         ps.lv = accel->sp_lv;
-        hipLaunchKernelGGL(k_traverse_spatial, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, ps, ray_in,
-                           (const float4*)accel->sp_nodes, (const float4*)accel->sp_pairs, (const float4*)accel->sp_quads,
-                           (const float4*)accel->sp_tris, dev->hit_records, dev->hit_ci, dev->queue_counter, order, st,
-                           (const uint32_t*)accel->ranks, dev->listed_rays, listed);
+#define RT_LAUNCH_SPATIAL(COUNT)                                                                                              \
+    hipLaunchKernelGGL((k_traverse_spatial<COUNT>), dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, ps, ray_in, \
+                       (const float4*)accel->sp_nodes, (const float4*)accel->sp_pairs, (const float4*)accel->sp_quads,          \
+                       (const float4*)accel->sp_tris, dev->hit_records, dev->hit_ci, dev->queue_counter, order, st,            \
+                       (const uint32_t*)accel->ranks, dev->listed_rays, listed, dev->walk_stats)
+        if (dev->walk_stats) RT_LAUNCH_SPATIAL(true);
+        else RT_LAUNCH_SPATIAL(false);
+#undef RT_LAUNCH_SPATIAL
         hipLaunchKernelGGL(k_traverse_quad, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in, nodes, pairs, quads,
                            st, dev->hit_records, dev->hit_ci, dev->queue_counter + 64, (const uint2*)dev->listed_rays,
                            (const uint32_t*)listed);
@@ -1444,6 +1462,12 @@ extern "C" {
 int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats) {
     if (!dev || (stats && stats->bytes < 32u)) return RT_ERR_INVALID_ARGUMENT;
     dev->trace_stats = stats ? (unsigned long long*)stats->ptr : nullptr;
+    return RT_OK;
+}
+
+int rt_device_set_walk_stats(rt_device* dev, rt_buffer* stats) {
+    if (!dev || (stats && stats->bytes < 32u)) return RT_ERR_INVALID_ARGUMENT;
+    dev->walk_stats = stats ? (unsigned long long*)stats->ptr : nullptr;
     return RT_OK;
 }
 

@@ -104,6 +104,11 @@ int rt_device_set_trace_kernel(rt_device* dev, int kernel);
 /* Instrumentation (no counterpart in the reference): how many rays of the device's last trace call the SPATIAL
  * kernel handed to the walk in the reference's order (0 after a call with another kernel). Waits for the stream. */
 int rt_device_listed_rays(rt_device* dev, uint32_t* count);
+/* Instrumentation (no counterpart in the reference): while a 32-byte buffer is set, every launch of the SPATIAL kernel
+ * adds {steps (one 64-byte record read and four boxes tested each), steps that hit none of the four, leaves whose
+ * triangles were tested, 0} as four uint64 to it; NULL turns it off. The kernel's own algorithmic bytes come from
+ * these counts. */
+int rt_device_set_walk_stats(rt_device* dev, rt_buffer* stats);
 /* Instrumentation (no counterpart in the reference): while enabled, every trace launch brackets its traversal
  * kernel with a pair of events on the device's stream. rt_device_traverse_timing waits for the pairs recorded
  * so far, returns the sum of their durations and their number, and forgets them. */

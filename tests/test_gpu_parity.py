@@ -375,6 +375,30 @@ def test_unevenly_filled_scenes_trace_exactly(device, oracle, kind, n):
     assert g[8]["rays_hit"] > 0, "some ray must hit"
 
 
+def test_walk_stats_count_the_walk_on_the_second_hierarchy(device, oracle):
+    """rt_device_set_walk_stats: steps, steps without a hit and leaves tested of the default traversal kernel; the
+    image is the same with and without counting, and the walk needs far fewer box tests than the reference's."""
+    from gpuraytracer_amd import capi
+    sc = _scene(20000)
+    buf = device.alloc(32)
+    capi.check(device.lib.rt_device_set_walk_stats(device.handle, buf.handle), "rt_device_set_walk_stats")
+    try:
+        g = _render_both(device, oracle, sc, 128, 72, 3, kernel=KERNEL_SPATIAL)
+    finally:
+        device.lib.rt_device_set_walk_stats(device.handle, None)
+    steps, empty, leaves, _ = [int(x) for x in buf.download(np.uint64, 4)]
+    buf.free()
+    assert g[2].view(np.uint32).tobytes() == g[3].view(np.uint32).tobytes()
+    rays = 128 * 72 * 3
+    print("per ray: %.1f steps (%.1f without a hit), %.1f leaves; the reference's walk: %.1f box tests" %
+          (steps / rays, empty / rays, leaves / rays, g[8]["nodes_visited"] / g[8]["rays"]))
+    assert 0 < leaves < steps and empty < steps
+    assert 4 * steps < g[8]["nodes_visited"], "four boxes per step: fewer box tests than the reference's walk"
+    small = device.alloc(16)
+    assert device.lib.rt_device_set_walk_stats(device.handle, small.handle) == capi.RT_ERR_INVALID_ARGUMENT
+    small.free()
+
+
 def test_invalid_trace_kernel_is_rejected(device):
     from gpuraytracer_amd import capi
     assert device.lib.rt_device_set_trace_kernel(device.handle, 4) == capi.RT_ERR_INVALID_ARGUMENT
