@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-counters", action="store_true",
+                    help="skip the frame that counts the reference's box and triangle tests (minutes at 50 M triangles); "
+                         "the roofline object then carries no algorithmic bytes")
     ap.add_argument("--no-reference-walk", action="store_true",
                     help="skip the two extra frames traced by the walk in the reference's order (reported beside `value`)")
     ap.add_argument("--dynamic", action="store_true", help="move the triangles on the device before every rebuild (always on for c5)")
@@ -226,12 +229,14 @@ def main():
             walk_buf.free()
 
         # exact traversal counters of one more frame (untimed, instrumented kernel variant)
-        stats_buf = dev.alloc(32)
-        dev.lib.rt_device_set_trace_stats(dev.handle, stats_buf.handle)
-        pipe.render(depth)
-        dev.sync()
-        dev.lib.rt_device_set_trace_stats(dev.handle, None)
-        nodes, tris, hits, counted = [int(x) for x in stats_buf.download(np.uint64, 4)]
+        nodes = tris = hits = counted = 0
+        if not args.no_counters:
+            stats_buf = dev.alloc(32)
+            dev.lib.rt_device_set_trace_stats(dev.handle, stats_buf.handle)
+            pipe.render(depth)
+            dev.sync()
+            dev.lib.rt_device_set_trace_stats(dev.handle, None)
+            nodes, tris, hits, counted = [int(x) for x in stats_buf.download(np.uint64, 4)]
         img = band.float().cpu().numpy()
 
     local_rays = num_rows * width * rpp

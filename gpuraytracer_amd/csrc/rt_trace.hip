@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                 }
                 if (in_reach) {
                     if (COUNT) n_leaves += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(true));
-                    const float4* t = reinterpret_cast<const float4*>(leaf_bytes + leaf * 128u);
+                    const float4* t = reinterpret_cast<const float4*>(leaf_bytes + (size_t)leaf * 128u);      // few per ray: 64-bit offsets cost nothing here
                     const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
                     const float2 places = *reinterpret_cast<const float2*>(t + 5);      // of the two triangles in the reference's order
                     const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                                 // The reference tests this triangle only if the box of ITS leaf of the triangle lets
                                 // the ray in: that leaf is the pair of neighbours in the reference's order.
                                 const uint32_t rank = __float_as_uint(k ? places.y : places.x);
-                                const float4* rt = reinterpret_cast<const float4*>(ref_leaf_bytes + (rank >> 1) * 128u);
+                                const float4* rt = reinterpret_cast<const float4*>(ref_leaf_bytes + (size_t)(rank >> 1) * 128u);
                                 const float entry = leaf_box_entry(org, inv_d, lim, rt[0], rt[1], rt[2], rt[3], rt[4]);
                                 if (entry < __builtin_inff()) {
                                     const float far_end = fmaxf(entry, hk.t);
@@ -1385,12 +1385,12 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     if (sort_rays) {
         // walk-length estimate from every fourth pair of nodes at depth 10 (or the deepest level above the leaves of a
         // small tree): deeper, smaller boxes tell long walks from short ones better than all the boxes of depth 8 do
-        // (on the library's own hierarchy walks are short and alike: all 32 pairs of depth 6 are enough to order them)
+        // (on the library's own hierarchy walks are short and alike: all 16 pairs of depth 5 are enough to order them)
         const bool on_spatial = spatial_kernel && !stats;
         const rt_levels& kl = on_spatial ? accel->sp_lv : p.lv;
         const uint32_t root_level = kl.count - 1u;
         static const uint32_t probe_depth_env = env_u32("GPURT_COST_DEPTH", 0u);
-        const uint32_t probe_depth = probe_depth_env >= 2u ? probe_depth_env : (on_spatial ? 6u : 10u);
+        const uint32_t probe_depth = probe_depth_env >= 2u ? probe_depth_env : (on_spatial ? 5u : 10u);
         const uint32_t depth = root_level > probe_depth ? probe_depth : (root_level > 1u ? root_level - 1u : 1u);
         const uint32_t nodes_there = kl.n[root_level - depth];
         static const uint32_t probe_stride_env = env_u32("GPURT_COST_STRIDE", 0u);
@@ -1427,7 +1427,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     // k_traverse_quad addresses its records and the leaves with 32-bit byte offsets
     const bool offsets_fit = rt_aligned_node_slots(&p.lv) * sizeof(rt_aabb) <= 0xffffffffull && (size_t)p.lv.n[0] * 128u <= 0xffffffffull;
     if (stats) RT_LAUNCH_TRAVERSE(true);
-    else if (spatial_kernel && offsets_fit && p.lv.count >= 3u && (size_t)accel->sp_lv.n[0] * 128u <= 0xffffffffull) {
+    else if (spatial_kernel && offsets_fit && p.lv.count >= 3u && accel->sp_lv.n[0] <= (1u << 25)) {      // (quad records within 4 GiB, leaf numbers within 28 bits)
         // first the walk on the library's own hierarchy, then the reference's walk for the rays it has listed
         uint32_t* listed = dev->queue_counter + 128;
         TraceParams ps = p;
