@@ -22,6 +22,7 @@ struct rth_settings
 	int32_t rebuild_every_cycle, fused_build;
 	uint32_t seed_raygen, seed_trace;
 	int32_t dynamic_scene;
+	int32_t reference_order_walk;
 };
 
 void rth_camera_matrices(const float* position, const float* focus, const float* up, float fov, float aspect, float near_z, float far_z,
@@ -116,6 +117,7 @@ static Settings ToSettings(const rth_settings* s)
 	r.FusedBuild = s->fused_build != 0;
 	r.SeedRayGen = s->seed_raygen; r.SeedTrace = s->seed_trace;
 	r.DynamicScene = s->dynamic_scene != 0;
+	r.ReferenceOrderWalk = s->reference_order_walk != 0;
 	return r;
 }
 

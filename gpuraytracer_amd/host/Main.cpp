@@ -4,7 +4,7 @@
 //
 //   rt_headless [--scene file.obj | --synthetic N] [--width W] [--height H] [--rpp R] [--depth D]
 //               [--cycles C] [--no-bvh] [--per-shader-build] [--rebuild] [--camera px py pz fx fy fz]
-//               [--seed S] [--gpu G] [--out image.ppm] [--pfm image.pfm] [--dynamic]
+//               [--seed S] [--gpu G] [--out image.ppm] [--pfm image.pfm] [--dynamic] [--reference-walk]
 //               [--resume state.bin] [--save-state state.bin]
 
 #include <chrono>
@@ -45,6 +45,7 @@ int main(int argc, char** argv)
 		else if (!std::strcmp(argv[i], "--out")) sOut = Next();
 		else if (!std::strcmp(argv[i], "--pfm")) sPFM = Next();
 		else if (!std::strcmp(argv[i], "--dynamic")) rtSettings.DynamicScene = true;
+		else if (!std::strcmp(argv[i], "--reference-walk")) rtSettings.ReferenceOrderWalk = true;
 		else if (!std::strcmp(argv[i], "--resume")) sResume = Next();
 		else if (!std::strcmp(argv[i], "--save-state")) sSaveState = Next();
 		else if (!std::strcmp(argv[i], "--camera"))

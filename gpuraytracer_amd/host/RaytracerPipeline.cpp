@@ -503,6 +503,8 @@ namespace RT::GraphicsAPI
 		if (!m_rtDevice) return false;
 		if (rtSettings) m_rtSettings = *rtSettings;
 		if (m_rtSettings.MaxRayDepth == 0 || m_rtSettings.MaxRaysPerPixel == 0) return false;
+		if (rt_device_set_trace_kernel(m_rtDevice, m_rtSettings.ReferenceOrderWalk ? RT_TRACE_KERNEL_QUAD : RT_TRACE_KERNEL_SPATIAL) != RT_OK)
+			return false;
 		m_rtSceneAABB = rtMeshData.SceneAABB;
 		if (m_rtSettings.DynamicScene)
 		{

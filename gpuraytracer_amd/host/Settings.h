@@ -62,6 +62,8 @@ namespace RT
 		bool FusedBuild = true;             //one fused LBVH build instead of one launch per reference dispatch
 		bool DynamicScene = false;          //the synthetic moving workload: before every cycle the triangles are moved on the
 		                                    //device (rt_synthetic_animate), the scene bounds reduced there and the tree rebuilt
+		bool ReferenceOrderWalk = false;    //trace by the walk of the reference's hierarchy in the reference's order
+		                                    //(RT_TRACE_KERNEL_QUAD) instead of the default on the library's own hierarchy
 		uint32_t SeedRayGen = 0;            //std::mt19937 seeds of the two host generators; 0 = std::random_device
 		uint32_t SeedTrace = 0;
 	};

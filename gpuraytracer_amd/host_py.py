@@ -16,7 +16,8 @@ class HostSettings(C.Structure):
                 ("aa_spread", C.c_float), ("dof_spread", C.c_float), ("use_bvh", C.c_int32), ("fov", C.c_float),
                 ("near_z", C.c_float), ("far_z", C.c_float), ("cam_position", C.c_float * 3), ("cam_focus", C.c_float * 3),
                 ("cam_up", C.c_float * 3), ("rebuild_every_cycle", C.c_int32), ("fused_build", C.c_int32),
-                ("seed_raygen", C.c_uint32), ("seed_trace", C.c_uint32), ("dynamic_scene", C.c_int32)]
+                ("seed_raygen", C.c_uint32), ("seed_trace", C.c_uint32), ("dynamic_scene", C.c_int32),
+                ("reference_order_walk", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -137,7 +138,7 @@ class HostPipeline:
     """RaytracerPipeline (C++) driven from Python: Initialize once, Render() per bounce."""
 
     def __init__(self, dev, mesh_source, width, height, camera, rpp=1, depth=3, aa=1.5, dof=0.0, use_bvh=True, fused_build=True,
-                 rebuild_every_cycle=False, seed_raygen=1, seed_trace=2, dynamic=False):
+                 rebuild_every_cycle=False, seed_raygen=1, seed_trace=2, dynamic=False, reference_order_walk=False):
         self.lib = load()
         self.dev = dev
         self.width, self.height = width, height
@@ -158,6 +159,7 @@ class HostPipeline:
         s.rebuild_every_cycle, s.fused_build = int(rebuild_every_cycle), int(fused_build)
         s.seed_raygen, s.seed_trace = seed_raygen, seed_trace
         s.dynamic_scene = int(dynamic)
+        s.reference_order_walk = int(reference_order_walk)
         self.handle = self.lib.rth_pipeline_create(dev.handle, mesh, C.byref(s))
         if not self.handle:
             raise RuntimeError("RaytracerPipeline::Initialize failed")

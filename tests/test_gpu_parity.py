@@ -545,15 +545,20 @@ def test_bvh_and_brute_force_images_agree(device, oracle):
     assert np.mean(np.any(np.abs(imgs[0] - imgs[1]) > 1e-5, axis=2)) < 0.01
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_cpp_host_pipeline_matches_oracle(device, oracle, fused):
-    """RaytracerPipeline (C++ host: own scene generator, camera maths, mt19937 seeds, stage sequencing)."""
+@pytest.mark.parametrize("fused,reference_walk", [(True, False), (False, False), (True, True)])
+def test_cpp_host_pipeline_matches_oracle(device, oracle, fused, reference_walk):
+    """RaytracerPipeline (C++ host: own scene generator, camera maths, mt19937 seeds, stage sequencing), with the default
+    traversal and with Settings::ReferenceOrderWalk."""
     from gpuraytracer_amd import host_py
     from gpuraytracer_amd.capi import aabb_dtype
     n, w, h, calls = 6000, 80, 45, 7
     sc = _scene(n)
-    hp = host_py.HostPipeline(device, n, w, h, sc["camera"], fused_build=fused, seed_raygen=1, seed_trace=2)
-    hp.render(calls)
+    hp = host_py.HostPipeline(device, n, w, h, sc["camera"], fused_build=fused, seed_raygen=1, seed_trace=2,
+                              reference_order_walk=reference_walk)
+    try:
+        hp.render(calls)
+    finally:
+        device.lib.rt_device_set_trace_kernel(device.handle, KERNEL_SPATIAL)     # the setting is the device's
     img, res = hp.output(), hp.result()
     count = oracle.load().orc_bvh_node_count(n)
     nodes = hp.read_buffer("bvh", aabb_dtype, count)
