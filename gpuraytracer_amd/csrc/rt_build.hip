@@ -1295,7 +1295,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
 
     // the library's own hierarchy: same triangles, same kernels, keys without overlapping bits. Only the traversal
     // kernel that walks it needs it.
-    a->sp_built = dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL && rt_spatial_slots(n) <= (1u << 25);      // (what its kernel can address)
+    a->sp_built = dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL && rt_spatial_slots(n) <= RT_SPATIAL_SLOTS_MAX;      // (what its kernel can address)
     if (!a->sp_built) return rt_launch_status();
     uint2* other = src == a->keys_a ? a->keys_b : a->keys_a;
     const SceneBounds spb = make_bounds(scene_min, scene_max);

@@ -122,13 +122,15 @@ static inline bool rt_make_levels(uint32_t num_prims, rt_levels* lv) {
     return true;
 }
 // Leaf slots of the library's own hierarchy for a scene of num_prims triangles: a power of two, so that every node
-// covers an aligned run of slots, and twice the leaves where that keeps the byte offsets of the 128-byte leaf
-// records within 32 bits - the room lets whole Morton cells start on aligned slots (see k_cell_choose).
+// covers an aligned run of slots, and twice the leaves while that stays within RT_SPATIAL_SLOTS_MAX - the room lets
+// whole Morton cells start on aligned slots (see k_cell_choose). The maximum is what k_traverse_spatial addresses:
+// its 64-byte records of four grandchildren by 32-bit byte offsets (2^25 records), its leaves by 28-bit numbers.
+constexpr uint32_t RT_SPATIAL_SLOTS_MAX = 1u << 26;
 static inline uint32_t rt_spatial_slots(uint32_t num_prims) {
     const uint32_t leaves = (num_prims + 1u) / 2u;
     uint32_t p = 2u;
     while (p < leaves) p <<= 1;
-    if (p <= (1u << 24)) p <<= 1;
+    if (p <= RT_SPATIAL_SLOTS_MAX / 2u) p <<= 1;
     return p;
 }
 constexpr uint32_t RT_CELL_BITS_MAX = 18u;     // finest Morton cells leaf slots are aligned to: 2^18

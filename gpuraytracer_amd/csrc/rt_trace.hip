@@ -1116,12 +1116,15 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                     intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
                     const bool may0 = (tmin_r <= h0.t) && (tmax_r > h0.t) && (h0.t <= reach);
                     const bool may1 = (ci1 != 0xffffffffu) && (tmin_r <= h1.t) && (tmax_r > h1.t) && (h1.t <= reach);
-                    if (may0 || may1) {
-#pragma unroll
-                        for (int k = 0; k < 2; k++) {
-                            const Hit hk = k ? h1 : h0;
+                    // few leaves have a triangle that is hit, fewer two: one turn of this loop per such triangle
+#pragma unroll 1
+                    for (uint32_t todo = (may0 ? 1u : 0u) | (may1 ? 2u : 0u); todo != 0u; todo &= todo - 1u) {
+                        {
+                            const bool k = (todo & 1u) == 0u;         // the second triangle's turn
+                            Hit hk;
+                            hk.t = k ? h1.t : h0.t; hk.u = k ? h1.u : h0.u; hk.v = k ? h1.v : h0.v; hk.w = k ? h1.w : h0.w;
                             const uint32_t ck = k ? ci1 : ci0;
-                            if ((k ? may1 : may0) && hk.t <= reach) {
+                            if (hk.t <= reach) {
                                 // The reference tests this triangle only if the box of ITS leaf of the triangle lets
                                 // the ray in: that leaf is the pair of neighbours in the reference's order.
                                 const uint32_t rank = __float_as_uint(k ? places.y : places.x);
@@ -1427,7 +1430,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     // k_traverse_quad addresses its records and the leaves with 32-bit byte offsets
     const bool offsets_fit = rt_aligned_node_slots(&p.lv) * sizeof(rt_aabb) <= 0xffffffffull && (size_t)p.lv.n[0] * 128u <= 0xffffffffull;
     if (stats) RT_LAUNCH_TRAVERSE(true);
-    else if (spatial_kernel && offsets_fit && p.lv.count >= 3u && accel->sp_lv.n[0] <= (1u << 25)) {      // (quad records within 4 GiB, leaf numbers within 28 bits)
+    else if (spatial_kernel && offsets_fit && p.lv.count >= 3u && accel->sp_lv.n[0] <= RT_SPATIAL_SLOTS_MAX) {
         // first the walk on the library's own hierarchy, then the reference's walk for the rays it has listed
         uint32_t* listed = dev->queue_counter + 128;
         TraceParams ps = p;
