@@ -157,10 +157,20 @@ def main():
         pipe.build = timed(raw_build, build_events)
         pipe.trace = timed(raw_trace, trace_events)
 
+        # The gather of a frame's rows runs beside the next frame's kernels: the rows are copied aside on the compute
+        # stream, and the collective reads that copy on a stream of its own. Every frame is gathered in full inside
+        # the timed region (the final synchronisation waits for the last one).
+        comm = torch.cuda.Stream() if world > 1 else None
+        aside = torch.empty_like(band) if world > 1 else None
+
         def step():
             pipe.render(depth)                       # one frame: build, camera rays, `depth` bounces
             if world > 1:
-                return gather_rows(band, height, width)
+                stream.wait_stream(comm)             # the previous frame's rows have left the copy
+                aside.copy_(band, non_blocking=True)
+                comm.wait_stream(stream)
+                with torch.cuda.stream(comm):
+                    return gather_rows(aside, height, width)
             return band
 
         for _ in range(args.warmup):
