@@ -282,8 +282,18 @@ __global__ __launch_bounds__(256) void k_spatial_keys(SceneBounds sb, const floa
 // 18, 15, ... 3 whose fullest cell still fits its slots (two triangles per slot); 0 = by rank, as the reference.
 // cells: see RT_CELLS_* in rt_internal.h; all of it is zero before k_cell_hist.
 __global__ __launch_bounds__(256) void k_cell_hist(uint32_t n, const uint2* __restrict__ sorted, uint32_t* __restrict__ cells) {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r < n) atomicAdd(cells + RT_CELLS_HIST + (sorted[r].x >> (30u - RT_CELL_BITS_MAX)), 1u);
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    // the keys are sorted: neighbouring lanes mostly fall into the same cell, and one lane per run of equal cells adds
+    // the run's length (one atomic per triangle on a word its neighbours want too costs ten times as much)
+    const uint32_t cell = r < n ? sorted[r].x >> (30u - RT_CELL_BITS_MAX) : 0xffffffffu;
+    const uint32_t before = (uint32_t)__shfl_up((int)cell, 1, 64);
+    const bool first = lane == 0u || cell != before;
+    const unsigned long long firsts = __builtin_amdgcn_ballot_w64(first);
+    if (first && r < n) {
+        const unsigned long long later = lane == 63u ? 0ull : firsts >> (lane + 1u);
+        const uint32_t run = later ? (uint32_t)__builtin_ctzll(later) + 1u : 64u - lane;
+        atomicAdd(cells + RT_CELLS_HIST + cell, run);
+    }
 }
 __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 #pragma unroll
@@ -808,14 +818,17 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
         store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
     }
     if (PACKED) {
-        s_rank[threadIdx.x] = (ranks && have) ? make_uint2(ranks[ci0 / 3u], two ? ranks[ci1 / 3u] : 0xffffffffu) : make_uint2(0u, 0u);
+        // (an empty slot - cell layout only - is marked: its record is never read, because no ray enters its box,
+        // and is not written)
+        s_rank[threadIdx.x] = (ranks && have) ? make_uint2(ranks[ci0 / 3u], two ? ranks[ci1 / 3u] : 0xffffffffu)
+                                              : make_uint2((cells && !have) ? 0xffffffffu : 0u, 0u);
         __syncthreads();
         const uint32_t first = blockIdx.x * 256u;
 #pragma unroll
         for (uint32_t i = 0; i < 8u; i++) {
             const uint32_t e = i * 256u + threadIdx.x;             // float4 e of the workgroup's 256 x 128 bytes
             const uint32_t leaf = e >> 3, j = e & 7u;
-            if (first + leaf < leaves)
+            if (first + leaf < leaves && s_rank[leaf].x != 0xffffffffu)
                 sorted_tris[RT_LEAF_STRIDE * (size_t)first + e] =
                     j < 5u ? s_tri[5u * leaf + j]
                            : (j == 5u ? make_float4(__uint_as_float(s_rank[leaf].x), __uint_as_float(s_rank[leaf].y), 0.0f, 0.0f)
