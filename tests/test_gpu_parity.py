@@ -375,6 +375,16 @@ def test_unevenly_filled_scenes_trace_exactly(device, oracle, kind, n):
     assert g[8]["rays_hit"] > 0, "some ray must hit"
 
 
+@pytest.mark.parametrize("n,w,h", [(250000, 192, 108), (1000000, 160, 90)])
+def test_large_scenes_against_the_oracle(device, oracle, n, w, h):
+    """The default traversal at sizes where the second hierarchy's leaf slots go by fine Morton cells (2^12 to 2^15;
+    1 M triangles is the benchmark's scene), on images small enough for the oracle: every buffer bit for bit."""
+    g = _render_both(device, oracle, _scene(n), w, h, 4, depth=4, kernel=KERNEL_SPATIAL)
+    for name, a, b in (("tone-mapped", g[0], g[1]), ("result", g[2], g[3]), ("emitted", g[4], g[5]), ("rays", g[6], g[7])):
+        assert a.view(np.uint32).tobytes() == b.view(np.uint32).tobytes(), "%s differs" % name
+    assert g[8]["rays_hit"] > 0
+
+
 def test_walk_stats_count_the_walk_on_the_second_hierarchy(device, oracle):
     """rt_device_set_walk_stats: steps, steps without a hit and leaves tested of the default traversal kernel; the
     image is the same with and without counting, and the walk needs far fewer box tests than the reference's."""
