@@ -912,7 +912,10 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
 //    entry of its box, or a closer hit whose box entry is beyond reach) goes on a list, and k_traverse_quad walks the
 //    listed rays again on the reference's hierarchy.
 // What stays out of reach of this argument is a triangle whose computed hit distance is closer than the closest hit
-// kept here although its boxes are entered beyond it: the reference may keep such a hit, this kernel never sees it.
+// kept here although its boxes are entered beyond it by more than the margin boxes are entered with (2^-10 of the
+// distance): the reference may keep such a hit, this kernel never sees it. Differences of a rounding - triangles in the
+// faces of flat boxes, overlapping coplanar triangles - are inside the margin and end on the list
+// (scripts/fuzz_walks.py compares the two walks over random scenes of that kind).
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const float4* __restrict__ rays, const float4* __restrict__ nodes,
                                                        const float4* __restrict__ pairs, const float4* __restrict__ quads,
@@ -947,6 +950,11 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
     // the smallest distance of any other hit seen, and whether the ray has to be walked again in the reference's order.
     uint32_t best_rank = 0xffffffffu;
     float reach = 0.0f, runner_up = 0.0f;
+    // Boxes are entered up to a little beyond reach: a triangle's hit distance and the entry distance of a box around
+    // it are two roundings of (nearly) the same number - the same one for a triangle in the face of a flat box - and
+    // a hit that is closer than the closest one by a rounding must not be lost behind a box that is farther by one.
+    float reach_in = 0.0f;
+    constexpr float kBeyond = 1.0009765625f;      // 1 + 2^-10
     bool have_hit = false, again = false;
     uint32_t h = 1u;                  // slot of the entered node
     unsigned long long trail = 0ull;
@@ -991,6 +999,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                             best.t = tmax_r; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
                             best_ci = 0u; best_rank = 0xffffffffu;
                             reach = tmax_r; runner_up = __builtin_inff();
+                            reach_in = reach * kBeyond;
                             have_hit = false; again = false;
                             // the trunk is entered on any box hit
                             bool walk = slab(org, inv_d, tmin_r, tmax_r, root_lo, root_hi) != 1e30f;
@@ -1046,10 +1055,10 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                 const float tn1 = vmax3(anx.y, any.y, anz.y), tx1 = vmin3(afx.y, afy.y, afz.y);
                 const float tn2 = vmax3(bnx.x, bny.x, bnz.x), tx2 = vmin3(bfx.x, bfy.x, bfz.x);
                 const float tn3 = vmax3(bnx.y, bny.y, bnz.y), tx3 = vmin3(bfx.y, bfy.y, bfz.y);
-                const bool hit0 = !(tx0 < vmax(tn0, lim)) && (tn0 <= reach);
-                const bool hit1 = !(tx1 < vmax(tn1, lim)) && (tn1 <= reach);
-                const bool hit2 = !(tx2 < vmax(tn2, lim)) && (tn2 <= reach);
-                const bool hit3 = !(tx3 < vmax(tn3, lim)) && (tn3 <= reach);
+                const bool hit0 = !(tx0 < vmax(tn0, lim)) && (tn0 <= reach_in);
+                const bool hit1 = !(tx1 < vmax(tn1, lim)) && (tn1 <= reach_in);
+                const bool hit2 = !(tx2 < vmax(tn2, lim)) && (tn2 <= reach_in);
+                const bool hit3 = !(tx3 < vmax(tn3, lim)) && (tn3 <= reach_in);
                 const uint32_t m = (hit0 ? 1u : 0u) | (hit1 ? 2u : 0u) | (hit2 ? 4u : 0u) | (hit3 ? 8u : 0u);
                 if (COUNT) {
                     n_steps += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(true));
@@ -1097,7 +1106,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
             if ((w & 15u) != 0u) {
                 // the oldest entry's next leaf; the entry goes when its last leaf is taken or its leaves lie beyond reach
                 const uint2 e = s_fifo[wait_head * 256u];
-                const bool in_reach = __uint_as_float(e.y) <= reach;
+                const bool in_reach = __uint_as_float(e.y) <= reach_in;
                 const uint32_t left = e.x >> 28, leaf = (e.x & 0x0fffffffu) + (uint32_t)__builtin_ctz(left);
                 const uint32_t rest = left & (left - 1u);
                 if (rest != 0u && in_reach) {
@@ -1138,6 +1147,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                                     } else if (have_hit ? far_end <= reach : far_end < tmax_r) {
                                         if (have_hit) runner_up = fminf(runner_up, best.t);
                                         best = hk; best_ci = ck; best_rank = rank; reach = far_end; have_hit = true;
+                                        reach_in = reach * kBeyond;
                                     } else if (have_hit) {
                                         again = true;          // a hit that is closer, behind a box entry that is not
                                     }

@@ -1,0 +1,108 @@
+"""Differential run of the two traversals over random scenes and cameras: the default kernel (the library's own
+hierarchy) against the walk in the reference's order, which returns the reference's closest hits by construction.
+Every buffer must agree bit for bit. Usage (GPU box): python scripts/fuzz_walks.py [cases] [seed]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gpuraytracer_amd import capi, host_py, scenes          # noqa: E402
+from gpuraytracer_amd.capi import vertex_dtype              # noqa: E402
+from gpuraytracer_amd.pipeline import Pipeline              # noqa: E402
+from gpuraytracer_amd.runtime import Device                 # noqa: E402
+
+
+def random_scene(rng):
+    """A triangle soup of a random kind: sizes from specks to slabs across the scene, axis-aligned quads (flat boxes,
+    shared edges), slivers (rays nearly in their plane), duplicates (equal distances)."""
+    n = int(10 ** rng.uniform(2.0, 5.3))
+    kind = rng.choice(["soup", "big", "quads", "slivers", "duplicates", "clusters", "inplane", "huge", "tiny"])
+    c = rng.uniform(-10, 10, (n, 1, 3))
+    if kind == "clusters":
+        c = rng.choice([-6.0, 0.0, 7.0], (n, 1, 3)) + rng.normal(0, 0.4, (n, 1, 3))
+    e = 20.0 / np.cbrt(n) * (8.0 if kind == "big" else 1.0)
+    off = rng.uniform(-e, e, (n, 3, 3))
+    if kind in ("quads", "inplane"):                      # triangles in axis-aligned planes of a 0.25 grid
+        axis = rng.randint(0, 3, n)
+        off[np.arange(n), :, axis] = 0.0
+        c = np.round(c * 4) / 4
+    if kind == "slivers":
+        off[:, 2] = off[:, 1] * rng.uniform(0.98, 1.02, (n, 1)) + rng.normal(0, e * 1e-3, (n, 3))
+    pos = (c + off).astype(np.float32)
+    if kind == "duplicates":
+        pos[n // 2:] = pos[:n - n // 2]
+        pos = pos[rng.permutation(n)]
+    v = np.zeros(3 * n, dtype=vertex_dtype)
+    v["position"] = pos.reshape(-1, 3)
+    v["normal"] = (0, 0, -1)
+    v["uv"] = rng.uniform(0, 1, (3 * n, 2)).astype(np.float32)
+    v["material_id"] = np.repeat(np.arange(n) % 8, 3)
+    idx = np.arange(3 * n, dtype=np.uint32)
+    atlas, ids = scenes.default_atlas()
+    smin, smax = scenes.centroid_bounds(v, idx)
+    scale = 1.0
+    if kind == "huge":                                    # coordinates binary16 cannot hold: the 16-bit boxes become infinite
+        scale = 5000.0
+    if kind == "tiny":                                    # determinants near the reference's 1e-6 cut-off
+        scale = 0.02
+    v["position"] *= np.float32(scale)
+    smin, smax = scenes.centroid_bounds(v, idx)
+    eye = rng.uniform(-12, 12, 3) * scale
+    if kind == "inplane":                                 # the camera in one of the planes: rays (nearly) inside flat boxes
+        eye = np.round(eye * 4) / 4
+    cam = dict(position=tuple(float(x) for x in eye), focus=tuple(float(x) for x in rng.uniform(-5, 5, 3) * scale), up=(0.0, 1.0, 0.0),
+               fov=float(rng.uniform(0.5, 1.6)), near_z=0.01 * scale, far_z=10000.0 * scale)
+    return dict(vertices=v, indices=idx, materials=scenes.synthetic_materials(), texture_ids=ids, atlas=atlas, scene_min=smin,
+                scene_max=smax, camera=cam, name="%s-%d" % (kind, n)), kind, n
+
+
+def run(dev, cases, seed, w=256, h=144, calls=4, depth=4, verbose=True):
+    """Traces `cases` random scenes with both kernels on device `dev`; returns (cases that differ, rays listed)."""
+    rng = np.random.RandomState(seed)
+    bad = 0
+    total_listed = 0
+    t0 = time.time()
+    for case in range(cases):
+        sc, kind, n = random_scene(rng)
+        cam = sc["camera"]
+        iv, ip = host_py.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], w / h, cam["near_z"], cam["far_z"])
+        got, listed = [], 0
+        for kernel in (3, 0):                               # RT_TRACE_KERNEL_SPATIAL, RT_TRACE_KERNEL_QUAD
+            capi.check(dev.lib.rt_device_set_trace_kernel(dev.handle, kernel), "rt_device_set_trace_kernel")
+            rs = iter(scenes.mt19937_raw(1, 6).reshape(-1, 3))
+            ts = iter(scenes.mt19937_raw(2, 3 * calls + 3).reshape(-1, 3))
+            p = Pipeline(dev, sc, w, h, iv, ip, rpp=1, depth=depth, raygen_seeds=lambda: next(rs), trace_seeds=lambda: next(ts))
+            for _ in range(calls):
+                p.render(1)
+                if kernel == 3:
+                    c = C.c_uint32(0)
+                    capi.check(dev.lib.rt_device_listed_rays(dev.handle, C.byref(c)), "rt_device_listed_rays")
+                    listed += c.value
+            got.append((p.result_image().copy(), p.emitted.download(np.float32, 4 * w * h).copy(), p.rays.download(np.float32, 8 * w * h).copy()))
+            p.close()
+        diff = sum(int(np.count_nonzero(np.any(a.reshape(w * h, -1).view(np.uint32) != b.reshape(w * h, -1).view(np.uint32), axis=1)))
+                   for a, b in zip(got[0], got[1]))
+        total_listed += listed
+        bad += diff != 0
+        if verbose or diff:
+            print("case %3d %-10s %7d triangles: %s, %d rays listed%s" % (case, kind, n, "same" if not diff else "%d ENTRIES DIFFER" % diff,
+                  listed, "" if case % 10 else "   (%.0f s)" % (time.time() - t0)), flush=True)
+    capi.check(dev.lib.rt_device_set_trace_kernel(dev.handle, 3), "rt_device_set_trace_kernel")
+    return bad, total_listed
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    w, h, calls = 256, 144, 4
+    bad, listed = run(Device(0), cases, seed, w, h, calls)
+    print("%d cases, %d with differences, %d rays listed in all (of %d traced)" % (cases, bad, listed, cases * calls * w * h))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
