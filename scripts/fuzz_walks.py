@@ -16,11 +16,31 @@ from gpuraytracer_amd.pipeline import Pipeline              # noqa: E402
 from gpuraytracer_amd.runtime import Device                 # noqa: E402
 
 
+def mesh_scene(rng):
+    """One of the reference's own meshes (as the golden fixtures hold them: shared edges and vertices, large walls) seen
+    from a random place."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    name = str(rng.choice(["testobject5_1", "testscene2"]))
+    g = np.load(os.path.join(gold, "oracle_%s.npz" % name))
+    v = g["vertices"]
+    lo, hi = v["position"].min(axis=0), v["position"].max(axis=0)
+    mid, half = (lo + hi) / 2, (hi - lo) / 2
+    eye = mid + rng.uniform(-1.2, 1.2, 3) * half
+    focus = mid + rng.uniform(-0.5, 0.5, 3) * half
+    cam = dict(position=tuple(float(x) for x in eye), focus=tuple(float(x) for x in focus), up=(0.0, 1.0, 0.0),
+               fov=float(rng.uniform(0.5, 1.6)), near_z=0.01, far_z=10000.0)
+    sc = dict(vertices=v, indices=np.arange(len(v), dtype=np.uint32), materials=g["materials"], texture_ids=g["texture_ids"],
+              atlas=g["atlas"], scene_min=g["scene_min"], scene_max=g["scene_max"], camera=cam, name=name)
+    return sc, "mesh", len(v) // 3
+
+
 def random_scene(rng):
     """A triangle soup of a random kind: sizes from specks to slabs across the scene, axis-aligned quads (flat boxes,
     shared edges), slivers (rays nearly in their plane), duplicates (equal distances)."""
     n = int(10 ** rng.uniform(2.0, 5.3))
-    kind = rng.choice(["soup", "big", "quads", "slivers", "duplicates", "clusters", "inplane", "huge", "tiny"])
+    kind = rng.choice(["soup", "big", "quads", "slivers", "duplicates", "clusters", "inplane", "huge", "tiny", "mesh"])
+    if kind == "mesh":
+        return mesh_scene(rng)
     c = rng.uniform(-10, 10, (n, 1, 3))
     if kind == "clusters":
         c = rng.choice([-6.0, 0.0, 7.0], (n, 1, 3)) + rng.normal(0, 0.4, (n, 1, 3))
