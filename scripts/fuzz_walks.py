@@ -1,6 +1,7 @@
 """Differential run of the two traversals over random scenes and cameras: the default kernel (the library's own
 hierarchy) against the walk in the reference's order, which returns the reference's closest hits by construction.
-Every buffer must agree bit for bit. Usage (GPU box): python scripts/fuzz_walks.py [cases] [seed]"""
+Every buffer must agree bit for bit. With a third argument "oracle" the default kernel is compared with the CPU oracle
+instead (test infrastructure; slower). Usage (GPU box): python scripts/fuzz_walks.py [cases] [seed] [oracle]"""
 import ctypes as C
 import os
 import sys
@@ -80,8 +81,12 @@ def random_scene(rng):
                 scene_max=smax, camera=cam, name="%s-%d" % (kind, n)), kind, n
 
 
-def run(dev, cases, seed, w=256, h=144, calls=4, depth=4, verbose=True):
-    """Traces `cases` random scenes with both kernels on device `dev`; returns (cases that differ, rays listed)."""
+def run(dev, cases, seed, w=256, h=144, calls=4, depth=4, verbose=True, against_oracle=False):
+    """Traces `cases` random scenes with both kernels on device `dev` (or with the default kernel and the oracle);
+    returns (cases that differ, rays listed)."""
+    oracle = None
+    if against_oracle:
+        from oracle import oracle_py as oracle
     rng = np.random.RandomState(seed)
     bad = 0
     total_listed = 0
@@ -91,7 +96,7 @@ def run(dev, cases, seed, w=256, h=144, calls=4, depth=4, verbose=True):
         cam = sc["camera"]
         iv, ip = host_py.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], w / h, cam["near_z"], cam["far_z"])
         got, listed = [], 0
-        for kernel in (3, 0):                               # RT_TRACE_KERNEL_SPATIAL, RT_TRACE_KERNEL_QUAD
+        for kernel in ((3,) if oracle else (3, 0)):         # RT_TRACE_KERNEL_SPATIAL, RT_TRACE_KERNEL_QUAD
             capi.check(dev.lib.rt_device_set_trace_kernel(dev.handle, kernel), "rt_device_set_trace_kernel")
             rs = iter(scenes.mt19937_raw(1, 6).reshape(-1, 3))
             ts = iter(scenes.mt19937_raw(2, 3 * calls + 3).reshape(-1, 3))
@@ -104,6 +109,11 @@ def run(dev, cases, seed, w=256, h=144, calls=4, depth=4, verbose=True):
                     listed += c.value
             got.append((p.result_image().copy(), p.emitted.download(np.float32, 4 * w * h).copy(), p.rays.download(np.float32, 8 * w * h).copy()))
             p.close()
+        if oracle:
+            op = oracle.Pipeline(sc, w, h, rpp=1, depth=depth, seed_raygen=1, seed_trace=2)
+            op.render(calls)
+            got.append((op.result().copy(), op.emitted().copy(), op.rays().view(np.float32).reshape(-1, 8).copy()))
+            op.close()
         diff = sum(int(np.count_nonzero(np.any(a.reshape(w * h, -1).view(np.uint32) != b.reshape(w * h, -1).view(np.uint32), axis=1)))
                    for a, b in zip(got[0], got[1]))
         total_listed += listed
@@ -119,7 +129,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     w, h, calls = 256, 144, 4
-    bad, listed = run(Device(0), cases, seed, w, h, calls)
+    bad, listed = run(Device(0), cases, seed, w, h, calls, against_oracle=len(sys.argv) > 3 and sys.argv[3] == "oracle")
     print("%d cases, %d with differences, %d rays listed in all (of %d traced)" % (cases, bad, listed, cases * calls * w * h))
     sys.exit(1 if bad else 0)
 
