@@ -1190,7 +1190,7 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {      // abcd -> a00b00
 __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float4* __restrict__ rays,
                                                   const float4* __restrict__ nodes, const float4* __restrict__ pairs,
                                                   uint32_t first_record, uint32_t num_records, uint32_t record_stride,
-                                                  uint32_t cost_shift, uint32_t cost_bits, uint2* __restrict__ keys) {
+                                                  uint32_t cost_shift, uint32_t cost_bits, uint32_t key_bits, uint2* __restrict__ keys) {
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     if (tid >= num_rays) return;
     const float4 lo = nodes[0], hi = nodes[1];
@@ -1206,7 +1206,17 @@ __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float
         touched += (bt0 != 1e30f ? 1u : 0u) + ((q0.y == q0.y) && (bt1 != 1e30f) ? 1u : 0u);
     }
     const uint32_t top_class = (1u << cost_bits) - 1u;
-    const uint32_t cost_class = min(touched >> cost_shift, top_class);
+    uint32_t cost_class = min(touched >> cost_shift, top_class);
+    if (num_records == 0u) {
+        // no probe: the length of the ray's segment inside the trunk's box, in units of the box's diagonal
+        const f3 t1 = mul(sub(mk(lo.x, lo.y, lo.z), org), inv_d), t2 = mul(sub(mk(lo.w, hi.x, hi.y), org), inv_d);
+        const float tn = fmaxf(fmaxf(fminf(t1.x, t2.x), fminf(t1.y, t2.y)), fmaxf(fminf(t1.z, t2.z), r1.z));
+        const float tf = fminf(fminf(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)), fminf(fmaxf(t1.z, t2.z), r1.w));
+        const f3 ext = sub(mk(lo.w, hi.x, hi.y), mk(lo.x, lo.y, lo.z));
+        const float diag = sqrtf(dot3(ext, ext)) * sqrtf(dot3(dir, dir));
+        const float part = fmaxf(tf - tn, 0.0f) / diag;           // NaN -> 0 below
+        cost_class = (uint32_t)fminf(fmaxf(part * (float)(top_class + 1u), 0.0f), (float)top_class);
+    }
     const float cx = (r0.x - lo.x) / (lo.w - lo.x), cy = (r0.y - lo.y) / (hi.x - lo.y), cz = (r0.z - lo.z) / (hi.y - lo.z);
     const uint32_t ox = (uint32_t)fminf(fmaxf(cx * 16.0f, 0.0f), 15.0f);
     const uint32_t oy = (uint32_t)fminf(fmaxf(cy * 16.0f, 0.0f), 15.0f);
@@ -1217,7 +1227,8 @@ __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float
     const uint32_t okey = spread3(ox) | (spread3(oy) << 1) | (spread3(oz) << 2);      // 12 bits
     const uint32_t dkey = spread3(dx) | (spread3(dy) << 1) | (spread3(dz) << 2);      // 6 bits
     // 24 bits: the (descending) cost class leads, the locality bits that still fit follow
-    keys[tid] = make_uint2(((top_class - cost_class) << (24u - cost_bits)) | (((okey << 6) | dkey) >> (cost_bits - 6u)), tid);
+    // (key_bits = 8: the class alone, one sorting pass - rays of a class keep the order they come in)
+    keys[tid] = make_uint2((((top_class - cost_class) << (24u - cost_bits)) | (((okey << 6) | dkey) >> (cost_bits - 6u))) >> (24u - key_bits), tid);
 }
 
 __global__ __launch_bounds__(256) void k_shade(TraceParams p, ShadeBuffers b, const float4* __restrict__ hit_records,
@@ -1405,16 +1416,23 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         static const uint32_t probe_depth_env = env_u32("GPURT_COST_DEPTH", 0u);
         const uint32_t probe_depth = probe_depth_env >= 2u ? probe_depth_env : (on_spatial ? 5u : 10u);
         const uint32_t depth = root_level > probe_depth ? probe_depth : (root_level > 1u ? root_level - 1u : 1u);
-        const uint32_t nodes_there = kl.n[root_level - depth];
+        // (... and better still, and nearly free: the length of the ray's way through the trunk's box; GPURT_COST_CHORD=0
+        // or a GPURT_COST_DEPTH bring the probe back)
+        static const uint32_t chord_env = env_u32("GPURT_COST_CHORD", 2u);
+        const bool chord_only = chord_env == 2u ? (on_spatial && probe_depth_env < 2u) : chord_env != 0u;
+        const uint32_t nodes_there = chord_only ? 0u : kl.n[root_level - depth];
         static const uint32_t probe_stride_env = env_u32("GPURT_COST_STRIDE", 0u);
         const uint32_t probe_stride = probe_stride_env ? probe_stride_env : (on_spatial ? 1u : 4u);
+        // sorting passes = bytes of the key that count (the class, then as much of the locality part as fits)
+        static const uint32_t key_passes_env = env_u32("GPURT_KEY_PASSES", 0u);
+        const uint32_t key_passes = key_passes_env < 1u ? (on_spatial ? 2u : 3u) : (key_passes_env > 3u ? 3u : key_passes_env);
         uint32_t cost_shift = 0u;
         while (((nodes_there / probe_stride) >> cost_shift) > (1u << cost_bits) - 1u) cost_shift++;
         key_nodes = on_spatial ? (const float4*)accel->sp_nodes : nodes;
         key_pairs = on_spatial ? (const float4*)accel->sp_pairs : pairs;
         hipLaunchKernelGGL(k_ray_keys, grid, block, 0, s, nr, ray_in, key_nodes, key_pairs, 1u << (depth - 1u), (nodes_there + 1u) / 2u,
-                           probe_stride, cost_shift, cost_bits, dev->ray_keys_a);
-        rc = rt_sort_pairs(dev, dev->ray_keys_a, dev->ray_keys_b, nr, 3u, &order);      // 24-bit keys
+                           probe_stride, cost_shift, key_passes == 1u ? 8u : cost_bits, 8u * key_passes, dev->ray_keys_a);
+        rc = rt_sort_pairs(dev, dev->ray_keys_a, dev->ray_keys_b, nr, key_passes, &order);      // 8, 16 or 24-bit keys
         if (rc) return rc;
     }
     // waiting leaves; the counting variant also keeps the entry distances of noted children, one row per depth
