@@ -916,6 +916,8 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
 // distance): the reference may keep such a hit, this kernel never sees it. Differences of a rounding - triangles in the
 // faces of flat boxes, overlapping coplanar triangles - are inside the margin and end on the list
 // (scripts/fuzz_walks.py compares the two walks over random scenes of that kind).
+constexpr uint32_t kStockFields = 14u;     // origin, direction, reciprocals, tmin, tmax, ray, first node, noted sibling
+
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const float4* __restrict__ rays, const float4* __restrict__ nodes,
                                                        const float4* __restrict__ pairs, const float4* __restrict__ quads,
@@ -931,6 +933,8 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
     const uint32_t first_leaf_grandparent = first_leaf >> 2;   // nodes from this slot on have leaves as grandchildren
     const bool odd_first = (root_level & 1u) != 0u;
     uint2* s_fifo = reinterpret_cast<uint2*>(s_dyn) + tid;     // [kFifo][256] waiting leaves, this lane's column
+    float* s_stock = reinterpret_cast<float*>(s_dyn + kFifo * 512u) + (tid >> 6) * (kStockFields * 64u);   // [14][64] this wave's rays to come
+    uint32_t stock_next = 0u, stock_count = 0u;                // wave-uniform: entries taken / held
     const float4 root_lo = nodes[0], root_hi = nodes[1];
     const char* quad_bytes = reinterpret_cast<const char*>(quads);
     const char* leaf_bytes = reinterpret_cast<const char*>(sorted_tris);
@@ -963,66 +967,92 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
     uint32_t n_steps = 0u, n_empty = 0u, n_leaves = 0u;    // COUNT: this wave's steps, steps that hit nothing, leaves tested
 
     for (;;) {
-        // 1. refill: every lane without a ray takes the next index; one atomic per wave (see k_traverse)
-        //    A refill stalls the whole wave for an atomic and two dependent loads, so it waits until several lanes are
-        //    free, unless nobody could walk meanwhile.
+        // 1. Lanes without a ray take one from the wave's stock in LDS. The stock is filled 64 rays at a time by the
+        //    whole wave - one atomic on the queue, the ray loads, the reciprocals and the test of the trunk's box done
+        //    by all lanes at once - so that taking a ray is a dozen LDS reads, worth doing for a few free lanes
+        //    already (a fill through the free lanes only, as in k_traverse_quad, has to wait for many of them).
         const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(w == kIdle);
         if (need_mask && ((uint32_t)__popcll(need_mask) >= p.refill_threshold || !__builtin_amdgcn_ballot_w64(w <= kFifo - 1u))) {
-            if (queues_tried >= 8u) {
-                if (w == kIdle) w = kDry;
-            } else {
+            while (stock_next == stock_count && queues_tried < 8u) {             // wave-uniform
                 const uint32_t q_begin = q * p.queue_chunk;
                 const uint32_t q_end = q_begin + p.queue_chunk;
-                const uint32_t leader = (uint32_t)__builtin_ctzll(need_mask);
                 uint32_t base = 0u;
-                if (lane == leader) base = atomicAdd(queue + 8u * q, (uint32_t)__popcll(need_mask));
-                base = q_begin + (uint32_t)__shfl((int)base, (int)leader, 64);
-                if (base >= q_end) {                               // wave-uniform: this queue is empty
+                if (lane == 0u) base = atomicAdd(queue + 8u * q, 64u);
+                base = q_begin + (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= q_end) {                               // this queue is empty
                     q = (q + 1u) & 7u;
                     queues_tried++;
-                } else if (w == kIdle) {
-                    const uint32_t mine = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
-                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
-                    if (mine < q_end) {
-                        const uint32_t slot = mine - q_begin;
-                        const uint32_t pos = (((slot >> p.deal_shift) * 8u + q) << p.deal_shift) | (slot & ((1u << p.deal_shift) - 1u));
-                        if (pos < p.num_rays) {
-                            const uint32_t rid = order ? order[pos].y : pos;
-                            const float4 r0 = rays[2 * (size_t)rid], r1 = rays[2 * (size_t)rid + 1];
-                            org = mk(r0.x, r0.y, r0.z); dir = mk(r0.w, r1.x, r1.y);
-                            tmin_r = r1.z; tmax_r = r1.w;
-                            lim = (tmin_r > 0.0f) ? tmin_r : __uint_as_float(1u);
-                            inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-                            inv_w = mk(dir.x == 0.0f ? copysignf(3.0e38f, inv_d.x) : inv_d.x, dir.y == 0.0f ? copysignf(3.0e38f, inv_d.y) : inv_d.y,
-                                       dir.z == 0.0f ? copysignf(3.0e38f, inv_d.z) : inv_d.z);
-                            neg_x = inv_w.x < 0.0f; neg_y = inv_w.y < 0.0f; neg_z = inv_w.z < 0.0f;
-                            best.t = tmax_r; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
-                            best_ci = 0u; best_rank = 0xffffffffu;
-                            reach = tmax_r; runner_up = __builtin_inff();
-                            reach_in = reach * kBeyond;
-                            have_hit = false; again = false;
-                            // the trunk is entered on any box hit
-                            bool walk = slab(org, inv_d, tmin_r, tmax_r, root_lo, root_hi) != 1e30f;
-                            h = 1u; trail = 0ull;
-                            if (walk && odd_first) {
-                                float bt0, bt1;
-                                slab_pair(org, inv_d, tmin_r, tmax_r, pairs[4], pairs[5], pairs[6], bt0, bt1);
-                                const bool hit0 = (bt0 != 1e30f) && (bt0 < best.t);
-                                const bool hit1 = (bt1 != 1e30f) && (bt1 < best.t);      // a missing child is NaNs: no hit
-                                walk = hit0 || hit1;
-                                h = hit0 ? 2u : 3u;
-                                trail = (hit0 && hit1) ? 8ull : 0ull;
-                            }
-                            if (walk) {
-                                ray = rid; w = 0u;
-                            } else {
-                                hit_records[rid] = make_float4(best.t, 0.0f, 0.0f, 0.0f);
-                                hit_ci[rid] = 0u;
-                            }
+                    continue;
+                }
+                const uint32_t mine = base + lane;
+                bool keep = false;
+                f3 c_org = mk(0.0f, 0.0f, 0.0f), c_dir = c_org, c_inv = c_org;
+                float c_tmin = 0.0f, c_tmax = 0.0f;
+                uint32_t c_rid = 0u, c_h = 1u, c_trail = 0u;
+                if (mine < q_end) {
+                    const uint32_t slot = mine - q_begin;
+                    const uint32_t pos = (((slot >> p.deal_shift) * 8u + q) << p.deal_shift) | (slot & ((1u << p.deal_shift) - 1u));
+                    if (pos < p.num_rays) {
+                        c_rid = order ? order[pos].y : pos;
+                        const float4 r0 = rays[2 * (size_t)c_rid], r1 = rays[2 * (size_t)c_rid + 1];
+                        c_org = mk(r0.x, r0.y, r0.z); c_dir = mk(r0.w, r1.x, r1.y);
+                        c_tmin = r1.z; c_tmax = r1.w;
+                        c_inv = mk(1.0f / c_dir.x, 1.0f / c_dir.y, 1.0f / c_dir.z);
+                        // the trunk is entered on any box hit
+                        keep = slab(c_org, c_inv, c_tmin, c_tmax, root_lo, root_hi) != 1e30f;
+                        if (keep && odd_first) {
+                            float bt0, bt1;
+                            slab_pair(c_org, c_inv, c_tmin, c_tmax, pairs[4], pairs[5], pairs[6], bt0, bt1);
+                            const bool hit0 = (bt0 != 1e30f) && (bt0 < c_tmax);
+                            const bool hit1 = (bt1 != 1e30f) && (bt1 < c_tmax);      // a missing child is NaNs: no hit
+                            keep = hit0 || hit1;
+                            c_h = hit0 ? 2u : 3u;
+                            c_trail = (hit0 && hit1) ? 8u : 0u;
+                        }
+                        if (!keep) {                               // nothing to walk: the ray's record is that of a miss
+                            hit_records[c_rid] = make_float4(c_tmax, 0.0f, 0.0f, 0.0f);
+                            hit_ci[c_rid] = 0u;
                         }
                     }
                 }
+                const unsigned long long kept = __builtin_amdgcn_ballot_w64(keep);
+                if (keep) {
+                    float* e = s_stock + __builtin_amdgcn_mbcnt_hi((uint32_t)(kept >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kept, 0u));
+                    e[0 * 64] = c_org.x; e[1 * 64] = c_org.y; e[2 * 64] = c_org.z;
+                    e[3 * 64] = c_dir.x; e[4 * 64] = c_dir.y; e[5 * 64] = c_dir.z;
+                    e[6 * 64] = c_inv.x; e[7 * 64] = c_inv.y; e[8 * 64] = c_inv.z;
+                    e[9 * 64] = c_tmin; e[10 * 64] = c_tmax;
+                    e[11 * 64] = __uint_as_float(c_rid); e[12 * 64] = __uint_as_float(c_h); e[13 * 64] = __uint_as_float(c_trail);
+                }
+                stock_next = 0u;
+                stock_count = (uint32_t)__popcll(kept);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
+            if (w == kIdle) {
+                const uint32_t at = stock_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+                if (at < stock_count) {
+                    const float* e = s_stock + at;
+                    org = mk(e[0 * 64], e[1 * 64], e[2 * 64]); dir = mk(e[3 * 64], e[4 * 64], e[5 * 64]);
+                    inv_d = mk(e[6 * 64], e[7 * 64], e[8 * 64]);
+                    tmin_r = e[9 * 64]; tmax_r = e[10 * 64];
+                    ray = __float_as_uint(e[11 * 64]); h = __float_as_uint(e[12 * 64]); trail = (unsigned long long)__float_as_uint(e[13 * 64]);
+                    lim = (tmin_r > 0.0f) ? tmin_r : __uint_as_float(1u);
+                    inv_w = mk(dir.x == 0.0f ? copysignf(3.0e38f, inv_d.x) : inv_d.x, dir.y == 0.0f ? copysignf(3.0e38f, inv_d.y) : inv_d.y,
+                               dir.z == 0.0f ? copysignf(3.0e38f, inv_d.z) : inv_d.z);
+                    neg_x = inv_w.x < 0.0f; neg_y = inv_w.y < 0.0f; neg_z = inv_w.z < 0.0f;
+                    best.t = tmax_r; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
+                    best_ci = 0u; best_rank = 0xffffffffu;
+                    reach = tmax_r; runner_up = __builtin_inff();
+                    reach_in = reach * kBeyond;
+                    have_hit = false; again = false;
+                    w = 0u;
+                } else if (queues_tried >= 8u) {
+                    w = kDry;                                      // no stock left and none to come
+                }
+            }
+            stock_next = min(stock_count, stock_next + (uint32_t)__popcll(need_mask));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         if (!__builtin_amdgcn_ballot_w64(w < kIdle)) {
             if (!__builtin_amdgcn_ballot_w64(w != kDry)) {            // queues empty and nothing in flight: the wave is done
@@ -1339,8 +1369,10 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     p.leaf_threshold = leaf_threshold < 1u ? 1u : (leaf_threshold > 64u ? 64u : leaf_threshold);
     static const uint32_t deal_shift_env = env_u32("GPURT_DEAL_SHIFT", 6u);
     static const uint32_t cost_bits = env_u32("GPURT_COST_BITS", 6u) < 6u ? 6u : (env_u32("GPURT_COST_BITS", 6u) > 12u ? 12u : env_u32("GPURT_COST_BITS", 6u));
-    static const uint32_t refill_threshold = env_u32("GPURT_REFILL_THRESHOLD", 16u);
-    p.refill_threshold = refill_threshold < 1u ? 1u : (refill_threshold > 64u ? 64u : refill_threshold);
+    // (free lanes that start a refill: taking rays from the spatial kernel's stock is cheap, a refill of the others is not)
+    static const uint32_t refill_threshold_env = env_u32("GPURT_REFILL_THRESHOLD", 0u);
+    const uint32_t refill_threshold = refill_threshold_env ? refill_threshold_env : (spatial_kernel ? 8u : 16u);
+    p.refill_threshold = refill_threshold > 64u ? 64u : refill_threshold;
     p.deal_shift = deal_shift_env < 6u ? 6u : (deal_shift_env > 20u ? 20u : deal_shift_env);
     const uint32_t deal_block = 1u << p.deal_shift;
     p.queue_chunk = ((((nr + deal_block - 1u) / deal_block) + 7u) / 8u) * deal_block;      // whole blocks, dealt to the eight queues in turn
@@ -1464,7 +1496,8 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         TraceParams ps = p;
         ps.lv = accel->sp_lv;
 #define RT_LAUNCH_SPATIAL(COUNT)                                                                                              \
-    hipLaunchKernelGGL((k_traverse_spatial<COUNT>), dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, ps, ray_in, \
+    hipLaunchKernelGGL((k_traverse_spatial<COUNT>), dim3(groups), block,                                                      \
+                       (size_t)(kFifo * 512u + 4u * kStockFields * 64u) * sizeof(uint32_t), s, ps, ray_in,                      \
                        (const float4*)accel->sp_nodes, (const float4*)accel->sp_pairs, (const float4*)accel->sp_quads,          \
                        (const float4*)accel->sp_tris, dev->hit_records, dev->hit_ci, dev->queue_counter, order, st,            \
                        (const uint32_t*)accel->ranks, dev->listed_rays, listed, dev->walk_stats)
