@@ -16,10 +16,12 @@
 //    ray; a lane that reaches a leaf notes it in a first-in first-out list and walks on, and the triangle tests
 //    run when enough lanes have one waiting; closest hits go to a 20-byte record and a second, fully convergent
 //    kernel shades them.
-//  * Three traversal kernels give the same buffers: k_traverse_quad (the default: two levels per step on 64-byte
-//    records of widened binary16 boxes, exact re-test at the leaves), k_traverse (one level per step on exact
-//    sibling pairs; its counting variant reproduces the reference's box-test count), k_trace (one thread per ray;
-//    also the brute-force path without a hierarchy).
+//  * Three traversal kernels walk the reference's hierarchy in the reference's order and give the same buffers by
+//    construction: k_traverse_quad (two levels per step on 64-byte records of widened binary16 boxes, exact
+//    re-test at the leaves), k_traverse (one level per step on exact sibling pairs; its counting variant reproduces
+//    the reference's box-test count), k_trace (one thread per ray; also the brute-force path without a hierarchy).
+//  * The default, k_traverse_spatial, finds the same closest hits on a second hierarchy of the library's own and hands
+//    the rays for which the reference's order could decide to k_traverse_quad (see the description at the kernel).
 //
 // Arithmetic conventions are those of rt_math.h; the slab test multiplies by one IEEE reciprocal of
 // each direction component per ray instead of dividing per box.
