@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_spatial_keys(SceneBounds sb, const floa
 // those boxes on every level. With more leaf slots than leaves (rt_spatial_slots) the leaves of every Morton cell of
 // 2^-T of the curve can start on a slot that is a multiple of slots / 2^T: then every node above that size IS a
 // cell (or half, or a quarter of one), and only inside a cell are leaves laid out by rank. T is the largest of
-// 18, 15, ... 3 whose fullest cell still fits its slots (two triangles per slot); 0 = by rank, as the reference.
+// 21, 18, ... 3 whose fullest cell still fits its slots (two triangles per slot); 0 = by rank, as the reference.
 // cells: see RT_CELLS_* in rt_internal.h; all of it is zero before k_cell_hist.
 __global__ __launch_bounds__(256) void k_cell_hist(uint32_t n, const uint2* __restrict__ sorted, uint32_t* __restrict__ cells) {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
@@ -300,61 +300,62 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
     for (int d = 1; d < 64; d <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
     return v;
 }
-// fullest cell at T = 18, 15 and 12, and the counts of the cells of T = 12; one thread per finest cell
+// With F = RT_CELL_BITS_MAX: fullest cell at T = F, F - 3 and F - 6, and the counts of the cells of T = F - 6; one thread
+// per finest cell
+constexpr uint32_t kCoarse = 1u << (RT_CELL_BITS_MAX - 6u);        // cells of the level one wave sums up
 __global__ __launch_bounds__(256) void k_cell_sums(uint32_t* __restrict__ cells) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
     uint32_t v = cells[RT_CELLS_HIST + i];
-    const uint32_t m18 = wave_max(v);
+    const uint32_t m0 = wave_max(v);
     v += (uint32_t)__shfl_xor((int)v, 1, 64); v += (uint32_t)__shfl_xor((int)v, 2, 64); v += (uint32_t)__shfl_xor((int)v, 4, 64);
-    const uint32_t m15 = wave_max(v);
+    const uint32_t m1 = wave_max(v);
     v += (uint32_t)__shfl_xor((int)v, 8, 64); v += (uint32_t)__shfl_xor((int)v, 16, 64); v += (uint32_t)__shfl_xor((int)v, 32, 64);
     if (lane == 0u) {
         // the wave's maxima go to the (still unused) table of cell starts; k_cell_choose gathers them: thousands of
         // atomics on three words would take longer than the rest of the build's bookkeeping together
         cells[RT_CELLS_HIST12 + (i >> 6)] = v;
-        cells[RT_CELLS_START + (i >> 6)] = m18;
-        cells[RT_CELLS_START + 4096u + (i >> 6)] = m15;
+        cells[RT_CELLS_START + (i >> 6)] = m0;
+        cells[RT_CELLS_START + kCoarse + (i >> 6)] = m1;
     }
 }
-// fullest cell at T = 9, 6 and 3, and the choice of T; one workgroup of 1024
+// fullest cells of the coarser levels (each the sum of eight of the level below), and the choice of T; one workgroup
+// of 1024
 __global__ __launch_bounds__(1024) void k_cell_choose(uint32_t* __restrict__ cells, uint32_t slots_log2, uint32_t t_cap) {
-    __shared__ uint32_t s9[512], s6[64], s3[8], s_max[3];
+    static_assert(RT_CELL_BITS_MAX == 21u, "the sums below go 15 -> 12 -> 9 -> 6 -> 3 bits");
+    __shared__ uint32_t s12[4096], s9[512], s6[64], s3[8], s_max[7];
     const uint32_t t = threadIdx.x;
-    __shared__ uint32_t s_fine[3];
-    if (t < 3u) { s_max[t] = 0u; s_fine[t] = 0u; }
+    if (t < 7u) s_max[t] = 0u;
     __syncthreads();
-    {   // fullest cells of T = 18, 15, 12 from the per-wave values of k_cell_sums
-        uint32_t m18 = 0u, m15 = 0u, m12 = 0u;
-        for (uint32_t j = t; j < 4096u; j += 1024u) {
-            m18 = max(m18, cells[RT_CELLS_START + j]);
-            m15 = max(m15, cells[RT_CELLS_START + 4096u + j]);
-            m12 = max(m12, cells[RT_CELLS_HIST12 + j]);
+    {   // fullest cells of T = 21, 18, 15 from the per-wave values of k_cell_sums
+        uint32_t m0 = 0u, m1 = 0u, m2 = 0u;
+        for (uint32_t j = t; j < kCoarse; j += 1024u) {
+            m0 = max(m0, cells[RT_CELLS_START + j]);
+            m1 = max(m1, cells[RT_CELLS_START + kCoarse + j]);
+            m2 = max(m2, cells[RT_CELLS_HIST12 + j]);
         }
-        m18 = wave_max(m18); m15 = wave_max(m15); m12 = wave_max(m12);
-        if ((t & 63u) == 0u) { atomicMax(&s_fine[0], m18); atomicMax(&s_fine[1], m15); atomicMax(&s_fine[2], m12); }
+        m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2);
+        if ((t & 63u) == 0u) { atomicMax(&s_max[0], m0); atomicMax(&s_max[1], m1); atomicMax(&s_max[2], m2); }
     }
-    if (t < 512u) {
+    for (uint32_t c = t; c < 4096u; c += 1024u) {
         uint32_t v = 0u;
-        for (uint32_t j = 0; j < 8u; j++) v += cells[RT_CELLS_HIST12 + 8u * t + j];
-        s9[t] = v;
+        for (uint32_t j = 0; j < 8u; j++) v += cells[RT_CELLS_HIST12 + 8u * c + j];
+        s12[c] = v;
+        atomicMax(&s_max[3], v);
     }
     __syncthreads();
-    if (t < 512u) atomicMax(&s_max[0], s9[t]);
-    if (t < 64u) { uint32_t v = 0u; for (uint32_t j = 0; j < 8u; j++) v += s9[8u * t + j]; s6[t] = v; }
+    if (t < 512u) { uint32_t v = 0u; for (uint32_t j = 0; j < 8u; j++) v += s12[8u * t + j]; s9[t] = v; atomicMax(&s_max[4], v); }
     __syncthreads();
-    if (t < 64u) atomicMax(&s_max[1], s6[t]);
-    if (t < 8u) { uint32_t v = 0u; for (uint32_t j = 0; j < 8u; j++) v += s6[8u * t + j]; s3[t] = v; }
+    if (t < 64u) { uint32_t v = 0u; for (uint32_t j = 0; j < 8u; j++) v += s9[8u * t + j]; s6[t] = v; atomicMax(&s_max[5], v); }
     __syncthreads();
-    if (t < 8u) atomicMax(&s_max[2], s3[t]);
+    if (t < 8u) { uint32_t v = 0u; for (uint32_t j = 0; j < 8u; j++) v += s6[8u * t + j]; s3[t] = v; atomicMax(&s_max[6], v); }
     __syncthreads();
     if (t == 0u) {
-        cells[1] = s_fine[0]; cells[2] = s_fine[1]; cells[3] = s_fine[2];
-        cells[4] = s_max[0]; cells[5] = s_max[1]; cells[6] = s_max[2];
         uint32_t chosen = 0u;
-        for (uint32_t k = 0; k < 6u && !chosen; k++) {
+        for (uint32_t k = 0; k < 7u; k++) {
+            cells[1u + k] = s_max[k];
             const uint32_t T = RT_CELL_BITS_MAX - 3u * k;
             // at least two slots per cell, and room for the fullest cell's triangles in its slots
-            if (T <= t_cap && T + 1u <= slots_log2 && cells[1u + k] <= 2u << (slots_log2 - T)) chosen = T;
+            if (!chosen && T <= t_cap && T + 1u <= slots_log2 && s_max[k] <= 2u << (slots_log2 - T)) chosen = T;
         }
         cells[0] = chosen;
     }

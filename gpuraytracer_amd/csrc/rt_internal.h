@@ -133,7 +133,7 @@ static inline uint32_t rt_spatial_slots(uint32_t num_prims) {
     if (p <= RT_SPATIAL_SLOTS_MAX / 2u) p <<= 1;
     return p;
 }
-constexpr uint32_t RT_CELL_BITS_MAX = 18u;     // finest Morton cells leaf slots are aligned to: 2^18
+constexpr uint32_t RT_CELL_BITS_MAX = 21u;     // finest Morton cells leaf slots are aligned to: 2^21
 // A leaf's two triangles take 80 bytes; leaves are laid out one per 128-byte line, because past the L2 a read costs
 // per line touched, not per byte (measured: random 128-byte records are fetched at the rate of 64-byte ones),
 // and an 80-byte stride makes every second leaf straddle two lines.
@@ -172,11 +172,11 @@ struct rt_accel {
     bool sp_built;             // the last build made it (builds on a device set to another traversal kernel do not)
     rt_levels sp_lv;           // shape of that hierarchy at the last build: rt_spatial_slots(num_prims) leaves, all levels full
 };
-// rt_accel::cells, in uint32 (everything before RT_CELLS_START is cleared by every build): [0..7] layout {cell bits T, largest cell at T = 18, 15, ...}; then the triangles per cell
-// of the finest level, the cells of level 12 summed from them, and the first rank of every cell at the chosen level
+// rt_accel::cells, in uint32 (everything before RT_CELLS_START is cleared by every build): [0..7] layout {cell bits T, largest cell at T = 21, 18, ... 3}; then the triangles per cell
+// of the finest level, the cells of 15 bits summed from them, and the first rank of every cell at the chosen level
 constexpr uint32_t RT_CELLS_HIST = 8u;
-constexpr uint32_t RT_CELLS_HIST12 = RT_CELLS_HIST + (1u << RT_CELL_BITS_MAX);
-constexpr uint32_t RT_CELLS_START = RT_CELLS_HIST12 + (1u << 12);
+constexpr uint32_t RT_CELLS_HIST12 = RT_CELLS_HIST + (1u << RT_CELL_BITS_MAX);          // cells of RT_CELL_BITS_MAX - 6 bits
+constexpr uint32_t RT_CELLS_START = RT_CELLS_HIST12 + (1u << (RT_CELL_BITS_MAX - 6u));
 // ... and, per axis, how many centroids fall into each of 4096 equal steps of the scene bounds, turned into the
 // 10-bit coordinate the keys are made of (k_axis_map)
 constexpr uint32_t RT_AXIS_STEPS = 4096u;
