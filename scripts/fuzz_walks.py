@@ -38,7 +38,7 @@ def mesh_scene(rng):
 def random_scene(rng):
     """A triangle soup of a random kind: sizes from specks to slabs across the scene, axis-aligned quads (flat boxes,
     shared edges), slivers (rays nearly in their plane), duplicates (equal distances)."""
-    n = int(10 ** rng.uniform(2.0, 5.3))
+    n = int(10 ** rng.uniform(2.0, float(os.environ.get("FUZZ_MAX_EXP", "5.3"))))
     kind = rng.choice(["soup", "big", "quads", "slivers", "duplicates", "clusters", "inplane", "huge", "tiny", "mesh"])
     if kind == "mesh":
         return mesh_scene(rng)
