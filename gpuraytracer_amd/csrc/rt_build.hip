@@ -1148,7 +1148,9 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
         if (e == hipSuccess) e = hipMalloc((void**)&a->pairs, (rt_aligned_node_slots(&lv) + 64u) * sizeof(rt_aabb));
         if (e == hipSuccess) e = hipMalloc((void**)&a->quads, rt_quad_records(&lv) * RT_QUAD_STRIDE * sizeof(float4));
     }
-    {   // the library's own hierarchy has rt_spatial_slots() leaf slots and all its levels full
+    // the library's own hierarchy has rt_spatial_slots() leaf slots and all its levels full; beyond what its kernel can
+    // address it is not made, and the walk in the reference's order traces such an accel
+    if (rt_spatial_slots(max_primitives) <= RT_SPATIAL_SLOTS_MAX) {
         const uint32_t slots = rt_spatial_slots(max_primitives);
         rt_levels sl;
         rt_make_levels(2u * slots, &sl);
@@ -1309,7 +1311,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
 
     // the library's own hierarchy: same triangles, same kernels, keys without overlapping bits. Only the traversal
     // kernel that walks it needs it.
-    a->sp_built = dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL && rt_spatial_slots(n) <= RT_SPATIAL_SLOTS_MAX;      // (what its kernel can address)
+    a->sp_built = dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL && a->sp_tris != nullptr;
     if (!a->sp_built) return rt_launch_status();
     uint2* other = src == a->keys_a ? a->keys_b : a->keys_a;
     const SceneBounds spb = make_bounds(scene_min, scene_max);
