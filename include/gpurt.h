@@ -187,7 +187,10 @@ int rt_generate_final_image(rt_device* dev, const rt_generate_final_image_info* 
  *      1 + 12 + ~log2(N) dependent dispatches of SortPrimitives::Sort and BuildBVH::Build,
  *      src/RaytracerPipeline.cpp:276-383, 475-562, with identical results) ---- */
 uint32_t rt_bvh_node_count(uint32_t num_primitives);     /* nodes the hierarchy uses; 0 if < 3 primitives */
-int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out); /* allocates every workspace once */
+/* Allocates every workspace once: packed triangles, sort keys, the private copies of the reference's hierarchy and,
+ * up to 2^26 leaf slots (about 67 M triangles), the library's own hierarchy for RT_TRACE_KERNEL_SPATIAL - about
+ * 1 KB per triangle in all. */
+int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out);
 int rt_accel_destroy(rt_accel* accel);
 /* Gathers Indices -> Vertices -> positions into the accel's packed triangle array
  * (3 x float4 per triangle, original order). Call after the mesh changes. */
