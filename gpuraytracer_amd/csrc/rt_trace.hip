@@ -914,7 +914,7 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
 //    entry of its box, or a closer hit whose box entry is beyond reach) goes on a list, and k_traverse_quad walks the
 //    listed rays again on the reference's hierarchy.
 // What stays out of reach of this argument is a triangle whose computed hit distance is closer than the closest hit
-// kept here although its boxes are entered beyond it by more than the margin boxes are entered with (2^-10 of the
+// kept here although its boxes are entered beyond it by more than the margin boxes are entered with (2^-8 of the
 // distance): the reference may keep such a hit, this kernel never sees it. Differences of a rounding - triangles in the
 // faces of flat boxes, overlapping coplanar triangles - are inside the margin and end on the list
 // (scripts/fuzz_walks.py compares the two walks over random scenes of that kind).
@@ -960,7 +960,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
     // it are two roundings of (nearly) the same number - the same one for a triangle in the face of a flat box - and
     // a hit that is closer than the closest one by a rounding must not be lost behind a box that is farther by one.
     float reach_in = 0.0f;
-    constexpr float kBeyond = 1.0009765625f;      // 1 + 2^-10
+    constexpr float kBeyond = 1.00390625f;      // 1 + 2^-8
     bool have_hit = false, again = false;
     uint32_t h = 1u;                  // slot of the entered node
     unsigned long long trail = 0ull;

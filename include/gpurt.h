@@ -91,7 +91,7 @@ int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats);
  * and shading. SPATIAL (default; rt_trace_rays_accel only, elsewhere it means QUAD) finds the same closest hit on a
  * second hierarchy that rt_accel_build makes from non-overlapping Morton codes, several times faster; rays for which
  * the reference's order could decide are walked again by QUAD. It can differ from the reference only where a triangle's
- * computed hit distance lies in front of every box around the triangle by more than 2^-10 of the distance and is
+ * computed hit distance lies in front of every box around the triangle by more than 2^-8 of the distance and is
  * closer than the closest hit found otherwise - see the kernel's description; no test or fuzzed scene has such a ray. rt_accel_build makes the second hierarchy only while the
  * device is set to SPATIAL; an accel built under another setting is traced by QUAD until it is built again. The
  * environment variable
