@@ -816,6 +816,27 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
             b.mx[0] = fmaxf(b.mx[0], px); b.mx[1] = fmaxf(b.mx[1], py); b.mx[2] = fmaxf(b.mx[2], pz);
         }
         if (PACKED) leaf_triangle_record(s_tri + 5u * threadIdx.x, corner, ci0, ci1);
+        if (cells) {
+            // The library's own hierarchy only: room around a sliver. The hit test of a triangle whose altitude is a
+            // tiny part of its longest edge is dominated by rounding near its long edges (its determinant is just
+            // above the reference's cut-off there), and accepts rays that pass beside the triangle's box; the
+            // reference finds such hits, because its leaf boxes hold an unrelated second triangle and are large. A box
+            // that is 1/32 of the longest edge wider on every side lets those rays test the triangle here too.
+            float pad = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const float* c0 = corner[3 * t]; const float* c1 = corner[3 * t + 1]; const float* c2 = corner[3 * t + 2];
+                const float e1[3] = {c1[0] - c0[0], c1[1] - c0[1], c1[2] - c0[2]}, e2[3] = {c2[0] - c0[0], c2[1] - c0[1], c2[2] - c0[2]};
+                const float e3[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
+                const float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                const float longest = fmaxf(fmaxf(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]),
+                                            e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]);
+                const float twice_area2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+                if (twice_area2 < longest * longest * (1.0f / 4096.0f)) pad = fmaxf(pad, sqrtf(longest) * (1.0f / 32.0f));      // altitude < longest / 64
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++) { b.mn[a] -= pad; b.mx[a] += pad; }
+        }
         store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
     }
     if (PACKED) {

@@ -39,7 +39,10 @@ def random_scene(rng):
     """A triangle soup of a random kind: sizes from specks to slabs across the scene, axis-aligned quads (flat boxes,
     shared edges), slivers (rays nearly in their plane), duplicates (equal distances)."""
     n = int(10 ** rng.uniform(2.0, float(os.environ.get("FUZZ_MAX_EXP", "5.3"))))
-    kind = rng.choice(["soup", "big", "quads", "slivers", "duplicates", "clusters", "inplane", "huge", "tiny", "mesh"])
+    kinds = ["soup", "big", "quads", "slivers", "duplicates", "clusters", "inplane", "huge", "tiny", "mesh"]
+    if os.environ.get("FUZZ_KINDS"):
+        kinds = os.environ["FUZZ_KINDS"].split(",")
+    kind = rng.choice(kinds)
     if kind == "mesh":
         return mesh_scene(rng)
     c = rng.uniform(-10, 10, (n, 1, 3))
@@ -81,7 +84,7 @@ def random_scene(rng):
                 scene_max=smax, camera=cam, name="%s-%d" % (kind, n)), kind, n
 
 
-def run(dev, cases, seed, w=256, h=144, calls=4, depth=4, verbose=True, against_oracle=False):
+def run(dev, cases, seed, w=256, h=144, calls=4, depth=4, verbose=True, against_oracle=False, only=None):
     """Traces `cases` random scenes with both kernels on device `dev` (or with the default kernel and the oracle);
     returns (cases that differ, rays listed)."""
     oracle = None
@@ -93,6 +96,8 @@ def run(dev, cases, seed, w=256, h=144, calls=4, depth=4, verbose=True, against_
     t0 = time.time()
     for case in range(cases):
         sc, kind, n = random_scene(rng)
+        if only is not None and case not in only:
+            continue
         cam = sc["camera"]
         iv, ip = host_py.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], w / h, cam["near_z"], cam["far_z"])
         got, listed = [], 0
@@ -118,6 +123,12 @@ def run(dev, cases, seed, w=256, h=144, calls=4, depth=4, verbose=True, against_
                    for a, b in zip(got[0], got[1]))
         total_listed += listed
         bad += diff != 0
+        if diff and only is not None:
+            for name, a, b in zip(("result", "emitted", "rays"), got[0], got[1]):
+                a2, b2 = a.reshape(w * h, -1), b.reshape(w * h, -1)
+                rows = np.nonzero(np.any(a2.view(np.uint32) != b2.view(np.uint32), axis=1))[0]
+                for r in rows[:8]:
+                    print("  %s[%d] (x %d, y %d): default %s | other %s" % (name, r, r % w, r // w, a2[r], b2[r]))
         if verbose or diff:
             print("case %3d %-10s %7d triangles: %s, %d rays listed%s" % (case, kind, n, "same" if not diff else "%d ENTRIES DIFFER" % diff,
                   listed, "" if case % 10 else "   (%.0f s)" % (time.time() - t0)), flush=True)
@@ -129,7 +140,8 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     w, h, calls = 256, 144, 4
-    bad, listed = run(Device(0), cases, seed, w, h, calls, against_oracle=len(sys.argv) > 3 and sys.argv[3] == "oracle")
+    only = {int(x) for x in os.environ["FUZZ_ONLY"].split(",")} if os.environ.get("FUZZ_ONLY") else None
+    bad, listed = run(Device(0), cases, seed, w, h, calls, against_oracle=len(sys.argv) > 3 and sys.argv[3] == "oracle", only=only)
     print("%d cases, %d with differences, %d rays listed in all (of %d traced)" % (cases, bad, listed, cases * calls * w * h))
     sys.exit(1 if bad else 0)
 
