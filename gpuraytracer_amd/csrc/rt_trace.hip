@@ -913,11 +913,14 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
 //  * a ray for which the order of the reference's walk could matter (another hit between the closest hit and the
 //    entry of its box, or a closer hit whose box entry is beyond reach) goes on a list, and k_traverse_quad walks the
 //    listed rays again on the reference's hierarchy.
-// What stays out of reach of this argument is a triangle whose computed hit distance is closer than the closest hit
-// kept here although its boxes are entered beyond it by more than the margin boxes are entered with (2^-8 of the
-// distance): the reference may keep such a hit, this kernel never sees it. Differences of a rounding - triangles in the
-// faces of flat boxes, overlapping coplanar triangles - are inside the margin and end on the list
-// (scripts/fuzz_walks.py compares the two walks over random scenes of that kind).
+// What stays out of reach of this argument are hits that are numerically false: a triangle whose computed hit distance
+// is closer than the closest hit kept here although its boxes are entered beyond it by more than the margin boxes are
+// entered with (2^-8 of the distance), or whose hit test accepts a ray that passes beside its box - near-degenerate
+// triangles seen edge-on, with a determinant just above the reference's cut-off (the build gives the boxes of slivers
+// some room for this reason). The reference may keep such a hit, this kernel never sees it. Differences of a rounding -
+// triangles in the faces of flat boxes, overlapping coplanar triangles - are inside the margin and end on the list
+// (scripts/fuzz_walks.py compares the two walks over random scenes of these kinds).
+
 constexpr uint32_t kStockFields = 14u;     // origin, direction, reciprocals, tmin, tmax, ray, first node, noted sibling
 
 template <bool COUNT>
