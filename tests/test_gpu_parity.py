@@ -402,6 +402,61 @@ def test_random_scenes_agree_between_the_two_walks(device):
     assert bad == 0
 
 
+def test_false_hit_beside_a_sliver_is_found_by_both_walks(device):
+    """The ray and the 1300:1 sliver of the one fuzzed case in which the two walks differed: Moeller-Trumbore accepts
+    the ray (determinant 2e-5) although it passes 1 % of the box size beside the triangle's bounding box. The walk in
+    the reference's order tests the triangle whenever the box of its leaf - the sliver and whatever triangle is next
+    to it in the reference's order - lets the ray in; the default kernel must then find the same hit."""
+    from gpuraytracer_amd import capi, scenes
+    from gpuraytracer_amd.capi import vertex_dtype
+    from gpuraytracer_amd.pipeline import Pipeline
+    sliver = np.array([[1.472400426864624, -0.08368708193302155, -1.4298924207687378],
+                       [1.6871155500411987, -0.3055894076824188, -2.033355474472046],
+                       [1.687436819076538, -0.30577898025512695, -2.033759355545044]], dtype=np.float32)
+    ray = np.array([-11.012279, 4.101115, -6.340874, 0.8997188, -0.31224802, 0.30497092, 0.0, 11814.092], dtype=np.float32)
+    found = 0
+    for seed in range(12):
+        rng = np.random.RandomState(seed)
+        n = 3000
+        pos = (rng.uniform(-10, 10, (n, 1, 3)) + rng.uniform(-0.2, 0.2, (n, 3, 3))).astype(np.float32)
+        # nothing but the sliver near the ray
+        o, d = ray[0:3].astype(np.float64), ray[3:6].astype(np.float64)
+        c = pos.mean(axis=1).astype(np.float64) - o
+        off = np.linalg.norm(c - np.outer(c @ d / (d @ d), d), axis=1)
+        pos = pos[off > 1.5]
+        pos[len(pos) // 2] = sliver
+        n = len(pos)
+        v = np.zeros(3 * n, dtype=vertex_dtype)
+        v["position"] = pos.reshape(-1, 3)
+        v["normal"] = (0, 0, -1)
+        v["material_id"] = np.repeat(np.arange(n) % 8, 3)
+        idx = np.arange(3 * n, dtype=np.uint32)
+        atlas, ids = scenes.default_atlas()
+        smin, smax = scenes.centroid_bounds(v, idx)
+        cam = dict(position=(0.0, 0.0, -30.0), focus=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=1.0, near_z=0.01, far_z=10000.0)
+        sc = dict(vertices=v, indices=idx, materials=scenes.synthetic_materials(), texture_ids=ids, atlas=atlas, scene_min=smin,
+                  scene_max=smax, camera=cam, name="sliver")
+        out = []
+        for kernel in (KERNEL_SPATIAL, KERNEL_QUAD):
+            capi.check(device.lib.rt_device_set_trace_kernel(device.handle, kernel), "rt_device_set_trace_kernel")
+            eye = np.eye(4, dtype=np.float32).reshape(-1)
+            p = Pipeline(device, sc, 8, 8, eye, eye, rpp=1, depth=1, raygen_seeds=lambda: (1, 2, 3), trace_seeds=lambda: (4, 5, 6))
+            try:
+                p.build()
+                p.camera_rays()
+                p.rays.upload(np.tile(ray, 64))
+                p.trace()
+                device.sync()
+                out.append(p.rays.download(np.float32, 8 * 64).reshape(64, 8).copy())
+            finally:
+                device.lib.rt_device_set_trace_kernel(device.handle, KERNEL_SPATIAL)
+                p.close()
+        assert out[0].view(np.uint32).tobytes() == out[1].view(np.uint32).tobytes(), "the walks differ (scene seed %d)" % seed
+        found += int(not np.array_equal(out[1][0], ray))
+    print("scenes in which the reference's walk takes the false hit:", found, "of 12")
+    assert found > 0, "no scene in which the reference's order lets the ray into the sliver's leaf: the test is empty"
+
+
 def test_walk_stats_count_the_walk_on_the_second_hierarchy(device, oracle):
     """rt_device_set_walk_stats: steps, steps without a hit and leaves tested of the default traversal kernel; the
     image is the same with and without counting, and the walk needs far fewer box tests than the reference's."""
