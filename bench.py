@@ -298,6 +298,8 @@ def main():
     }
     if ref_walk:
         out["reference_order_walk"] = ref_walk
+        # lbvh_build_ms is what a frame pays: the reference's hierarchy and the library's own; this is the former alone
+        out["reference_lbvh_build_ms"] = ref_walk["lbvh_build_ms"]
     if walk:
         # what k_traverse_spatial itself reads and writes per launch in its own layout: 32 B ray + 8 B order entry in,
         # 20 B hit record out, 48 B of a 64-byte record per step, 88 B of a leaf record per leaf tested
