@@ -27,6 +27,7 @@ RT_ERR_INVALID_ARGUMENT = 1
 RT_ERR_TOO_FEW_PRIMITIVES = 2
 RT_ERR_BUFFER_TOO_SMALL = 3
 RT_ERR_OUT_OF_MEMORY = 4
+RT_ERR_LIMIT_EXCEEDED = 5
 
 # numpy views of the element layouts (shader/Raytracer.hlsli:15-40 of the reference)
 vertex_dtype = np.dtype([("position", "<f4", 3), ("uv", "<f4", 2), ("normal", "<f4", 3), ("tangent", "<f4", 3),
@@ -124,6 +125,7 @@ SIGNATURES = {
     "rt_device_listed_rays": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "rt_device_set_walk_stats": (C.c_int, [_P, _P]),
     "rt_scene_bounds": (C.c_int, [_P, _U32, _P, _P, _P]),
+    "rt_scene_bounds_static": (C.c_int, [_P, _U32, _P, _P, _P]),
     "rt_accel_pack_bounds": (C.c_int, [_P, _U32, _P, _P, _P]),
     "rt_accel_build_device_bounds": (C.c_int, [_P, _P, _P, _P]),
     "rt_synthetic_animate": (C.c_int, [_P, _U32, _U32, _P, _P]),

@@ -11,10 +11,31 @@
 //
 // Built with -ffp-contract=off: the Morton quantisation must round once per written operation.
 
+#include <atomic>
 #include <new>
 
 #include "rt_internal.h"
 #include "rt_math.h"
+
+// Scratch of rt_scene_bounds_static, the entry point that allocates nothing: the per-workgroup partial bounds of the
+// centroid reduction (k_bounds_partial -> k_bounds_finish), RT_BOUNDS_BLOCKS x 6 floats = 24 KiB, resident on every GPU
+// the library runs on until the process ends. In host code the array's name is only a stand-in for the symbol; its
+// address on a device comes from hipGetSymbolAddress with that device current (rt_static_scratch_init, called by
+// rt_device_create) and is what the kernels are given.
+#define RT_BOUNDS_BLOCKS 1024u
+static __device__ __align__(256) float scratch[RT_BOUNDS_BLOCKS * 6u];
+constexpr int kStaticScratchDevices = 64;
+static std::atomic<float*> g_scratch_ptr[kStaticScratchDevices];
+
+int rt_static_scratch_init(int gpu) {
+    if (gpu < 0 || gpu >= kStaticScratchDevices) return RT_OK;      // such a device has no static scratch; its entry point says so
+    if (g_scratch_ptr[gpu].load(std::memory_order_acquire)) return RT_OK;
+    float* p = nullptr;
+    RT_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));   // the current device's copy of the array
+    if (!p) return RT_ERR_HIP_BASE + (int)hipErrorInvalidSymbol;
+    g_scratch_ptr[gpu].store(p, std::memory_order_release);
+    return RT_OK;
+}
 
 namespace {
 
@@ -80,7 +101,7 @@ __global__ __launch_bounds__(256) void k_pack(uint32_t n, const uint32_t* __rest
 // min / max over ((p1 + p2) + p3) * (1/3). min and max are exact, so the order of the reduction does not matter
 // for finite positions. Stage one: every workgroup strides over the triangles and leaves its bounds in
 // partials[block][6]; PACK also writes the packed triangle array (k_pack). Stage two reduces the partials.
-constexpr uint32_t kBoundsBlocks = 1024u;
+constexpr uint32_t kBoundsBlocks = RT_BOUNDS_BLOCKS;
 
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_bounds_partial(uint32_t n, const uint32_t* __restrict__ indices,
@@ -1231,25 +1252,29 @@ int bounds_workspace(rt_device* dev) {
     return RT_OK;
 }
 
-// centroid bounds of n triangles into bounds[0..7]; tris != nullptr also writes the packed triangle array
-int launch_bounds(rt_device* dev, uint32_t n, const rt_buffer* indices, const rt_buffer* vertices, float4* tris, rt_buffer* bounds) {
+// centroid bounds of n triangles into bounds[0..7]; tris != nullptr also writes the packed triangle array.
+// partials: kBoundsBlocks x 6 floats of scratch; nullptr = the device's own workspace, allocated on first use
+int launch_bounds(rt_device* dev, uint32_t n, const rt_buffer* indices, const rt_buffer* vertices, float4* tris, rt_buffer* bounds,
+                  float* partials = nullptr) {
     if (indices->bytes < (size_t)n * 12u || bounds->bytes < 32u) return RT_ERR_BUFFER_TOO_SMALL;
     int rc = rt_set_device(dev);
     if (rc) return rc;
-    rc = bounds_workspace(dev);
-    if (rc) return rc;
+    if (!partials) {
+        rc = bounds_workspace(dev);
+        if (rc) return rc;
+        partials = dev->bounds_partials;
+    }
     uint32_t blocks = div_up(n, 256u);
     if (blocks > kBoundsBlocks) blocks = kBoundsBlocks;
     if (blocks) {
         if (tris)
             hipLaunchKernelGGL((k_bounds_partial<true>), dim3(blocks), dim3(256), 0, dev->stream, n, (const uint32_t*)indices->ptr,
-                               (const rt_vertex*)vertices->ptr, tris, dev->bounds_partials);
+                               (const rt_vertex*)vertices->ptr, tris, partials);
         else
             hipLaunchKernelGGL((k_bounds_partial<false>), dim3(blocks), dim3(256), 0, dev->stream, n, (const uint32_t*)indices->ptr,
-                               (const rt_vertex*)vertices->ptr, (float4*)nullptr, dev->bounds_partials);
+                               (const rt_vertex*)vertices->ptr, (float4*)nullptr, partials);
     }
-    hipLaunchKernelGGL(k_bounds_finish, dim3(1), dim3(256), 0, dev->stream, blocks, (const float*)dev->bounds_partials,
-                       (float*)bounds->ptr);
+    hipLaunchKernelGGL(k_bounds_finish, dim3(1), dim3(256), 0, dev->stream, blocks, (const float*)partials, (float*)bounds->ptr);
     return rt_launch_status();
 }
 
@@ -1263,6 +1288,18 @@ int rt_scene_bounds(rt_device* dev, uint32_t num_primitives, const rt_buffer* in
     if (!dev || !indices || !vertices || !bounds) return RT_ERR_INVALID_ARGUMENT;
     if (num_primitives > 0x55555555u) return RT_ERR_INVALID_ARGUMENT;
     return launch_bounds(dev, num_primitives, indices, vertices, nullptr, bounds);
+}
+
+int rt_scene_bounds_static(rt_device* dev, uint32_t num_primitives, const rt_buffer* indices, const rt_buffer* vertices,
+                           rt_buffer* bounds) {
+    if (!dev || !indices || !vertices || !bounds) return RT_ERR_INVALID_ARGUMENT;
+    if (num_primitives > RT_SCENE_BOUNDS_STATIC_MAX_PRIMITIVES) return RT_ERR_LIMIT_EXCEEDED;
+    // the address of this device's copy of the scratch array, looked up when the device was created
+    float* partials = (dev->gpu >= 0 && dev->gpu < kStaticScratchDevices) ? g_scratch_ptr[dev->gpu].load(std::memory_order_acquire) : nullptr;
+    if (!partials) return RT_ERR_LIMIT_EXCEEDED;                      // GPU index beyond the table of scratch addresses
+    // Nothing has to be cleared: the first launch overwrites partials [0, blocks) and the second reads exactly those,
+    // whatever an earlier (larger) call left behind them.
+    return launch_bounds(dev, num_primitives, indices, vertices, nullptr, bounds, partials);
 }
 
 int rt_accel_pack_bounds(rt_accel* a, uint32_t num_primitives, const rt_buffer* indices, const rt_buffer* vertices,

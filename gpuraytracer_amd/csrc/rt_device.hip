@@ -53,6 +53,8 @@ int rt_device_create(int gpu_index, rt_device** out) {
     if (e != hipSuccess) { delete d; return RT_ERR_HIP_BASE + (int)e; }
     e = hipMalloc((void**)&d->sort_totals, 512 * sizeof(uint32_t));
     if (e != hipSuccess) { (void)hipStreamDestroy(d->stream); delete d; return RT_ERR_HIP_BASE + (int)e; }
+    const int src = rt_static_scratch_init(gpu_index);      // this GPU is current: the address of its static scratch
+    if (src) { (void)hipFree(d->sort_totals); (void)hipStreamDestroy(d->stream); delete d; return src; }
     *out = d;
     return RT_OK;
 }
@@ -109,6 +111,7 @@ const char* rt_error_string(int code) {
         case RT_ERR_TOO_FEW_PRIMITIVES: return "fewer than 3 primitives";
         case RT_ERR_BUFFER_TOO_SMALL: return "buffer too small";
         case RT_ERR_OUT_OF_MEMORY: return "out of memory";
+        case RT_ERR_LIMIT_EXCEEDED: return "size beyond the fixed limit of an entry point that allocates nothing";
         default: break;
     }
     if (code >= RT_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(code - RT_ERR_HIP_BASE));

@@ -81,6 +81,9 @@ static inline bool rt_rows_fit(uint32_t first_row, uint32_t num_rows, uint32_t r
 #define RT_SORT_TILE (RT_SORT_THREADS * RT_SORT_ITEMS)
 
 int rt_sort_workspace(rt_device* dev, uint32_t num_elements);   // grows dev->sort_table as needed
+// Looks up, once per GPU and with that GPU current, the device address of the static scratch array behind
+// rt_scene_bounds_static (defined beside the array in rt_build.hip); rt_device_create calls it.
+int rt_static_scratch_init(int gpu);
 // Stable LSD radix sort of (key, value) pairs by the low 8 * passes key bits, queued on the device's stream.
 // a and b hold n pairs each and are both overwritten; *sorted receives whichever of them holds the result.
 int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted);

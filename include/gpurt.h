@@ -30,6 +30,7 @@ extern "C" {
 #define RT_ERR_TOO_FEW_PRIMITIVES 2 /* fewer than 3 triangles: the reference's level loop never ends */
 #define RT_ERR_BUFFER_TOO_SMALL 3
 #define RT_ERR_OUT_OF_MEMORY 4
+#define RT_ERR_LIMIT_EXCEEDED 5     /* beyond the fixed limit of an entry point that allocates nothing */
 #define RT_ERR_HIP_BASE 0x1000      /* 0x1000 + hipError_t */
 
 typedef struct rt_device rt_device;
@@ -204,6 +205,16 @@ int rt_accel_pack(rt_accel* accel, uint32_t num_primitives, const rt_buffer* ind
  * +-FLT_MAX as the host loop does. */
 int rt_scene_bounds(rt_device* dev, uint32_t num_primitives, const rt_buffer* indices, const rt_buffer* vertices,
                     rt_buffer* bounds);
+/* rt_scene_bounds for callers that cannot allocate: code under HIP graph capture, tight per-frame loops, harnesses
+ * that forbid hipMalloc. No counterpart in the reference. Same arguments, same result bit for bit, but the reduction's
+ * scratch (per-workgroup partial bounds, 24 KiB) is a static device array that every GPU the library runs on holds
+ * until the process ends, so the call never allocates or frees (rt_scene_bounds allocates its scratch on a device's
+ * first call). Limits: num_primitives <= RT_SCENE_BOUNDS_STATIC_MAX_PRIMITIVES and a GPU index below 64, else
+ * RT_ERR_LIMIT_EXCEEDED. All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
+ * device handles of the same GPU) race; calls on one stream are ordered and need no clearing in between. */
+#define RT_SCENE_BOUNDS_STATIC_MAX_PRIMITIVES 0x55555555u   /* 3 * count must fit the 32-bit index arithmetic */
+int rt_scene_bounds_static(rt_device* dev, uint32_t num_primitives, const rt_buffer* indices, const rt_buffer* vertices,
+                           rt_buffer* bounds);
 /* rt_accel_pack and rt_scene_bounds in one pass over the mesh. */
 int rt_accel_pack_bounds(rt_accel* accel, uint32_t num_primitives, const rt_buffer* indices, const rt_buffer* vertices,
                          rt_buffer* bounds);
