@@ -206,6 +206,7 @@ def main():
         kernel_name = os.environ.get("GPURT_TRACE_KERNEL", "") or "spatial"
         if kernel_name == "spatial" and world == 1 and not args.no_reference_walk:
             dev.lib.rt_device_set_trace_kernel(dev.handle, 0)        # RT_TRACE_KERNEL_QUAD
+            dev.lib.rt_accel_set_second_hierarchy(pipe.accel.handle, 0, 21)      # that walk never reads it
             pipe.render(depth)
             torch.cuda.synchronize()
             dev.lib.rt_device_set_traverse_timing(dev.handle, 1)
@@ -223,6 +224,7 @@ def main():
             dev.lib.rt_device_traverse_timing(dev.handle, ctypes.byref(rk_ms), ctypes.byref(rk_n))
             dev.lib.rt_device_set_traverse_timing(dev.handle, 0)
             dev.lib.rt_device_set_trace_kernel(dev.handle, 3)        # RT_TRACE_KERNEL_SPATIAL
+            dev.lib.rt_accel_set_second_hierarchy(pipe.accel.handle, 1, 21)
             ref_walk = {"kernel": "k_traverse_quad", "value": round(width * height * rpp * depth * 2 / ref_elapsed / 1e6, 3),
                         "unit": "Mrays/s", "steps": 2, "avg_launch_ms": round(rk_ms.value / max(rk_n.value, 1), 4),
                         "lbvh_build_ms": round(float(np.mean([a.elapsed_ms(b) for a, b in ref_build_events])), 4)}

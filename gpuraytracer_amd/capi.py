@@ -72,6 +72,12 @@ class ImageRows(C.Structure):
     _fields_ = [("first_row", C.c_uint32), ("num_rows", C.c_uint32), ("row_stride", C.c_uint32)]
 
 
+class TraceTuning(C.Structure):
+    """rt_trace_tuning: knobs of the persistent traversal kernels (no setting changes a result)."""
+    _fields_ = [(n, C.c_uint32) for n in ("leaf_threshold", "refill_threshold", "blocks_per_cu", "sort_rays", "deal_shift",
+                                          "cost_bits", "cost_depth", "cost_stride", "cost_chord", "key_passes")]
+
+
 class GenerateFinalImageInfo(C.Structure):
     _fields_ = [("screen_dimensions", C.c_int32 * 2), ("max_rays_per_pixel", C.c_uint32), ("num_samples", C.c_uint32)]
 
@@ -123,6 +129,10 @@ SIGNATURES = {
     "rt_accel_build": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
     "rt_device_set_trace_kernel": (C.c_int, [_P, C.c_int]),
     "rt_device_listed_rays": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    "rt_device_set_slab_division": (C.c_int, [_P, C.c_int]),
+    "rt_device_get_trace_tuning": (C.c_int, [_P, C.POINTER(TraceTuning)]),
+    "rt_device_set_trace_tuning": (C.c_int, [_P, C.POINTER(TraceTuning)]),
+    "rt_accel_set_second_hierarchy": (C.c_int, [_P, C.c_int, _U32]),
     "rt_device_set_walk_stats": (C.c_int, [_P, _P]),
     "rt_scene_bounds": (C.c_int, [_P, _U32, _P, _P, _P]),
     "rt_scene_bounds_static": (C.c_int, [_P, _U32, _P, _P, _P]),

@@ -1178,6 +1178,8 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
     a->pairs = a->sp_pairs = a->sp_nodes = nullptr;
     a->ranks = a->cells = nullptr;
     a->sp_built = false;
+    a->want_spatial = true;
+    a->cell_bits_cap = RT_CELL_BITS_MAX;
     const size_t tri_bytes = (size_t)max_primitives * 48u, key_bytes = (size_t)max_primitives * 8u;
     hipError_t e = hipMalloc((void**)&a->tris, tri_bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&a->sorted_tris, ((size_t)max_primitives + 1u) / 2u * RT_LEAF_STRIDE * sizeof(float4));
@@ -1229,6 +1231,13 @@ int rt_accel_destroy(rt_accel* a) {
     if (a->ranks) (void)hipFree(a->ranks);
     if (a->cells) (void)hipFree(a->cells);
     delete a;
+    return RT_OK;
+}
+
+int rt_accel_set_second_hierarchy(rt_accel* a, int enable, uint32_t cell_bits) {
+    if (!a) return RT_ERR_INVALID_ARGUMENT;
+    a->want_spatial = enable != 0;
+    a->cell_bits_cap = cell_bits > RT_CELL_BITS_MAX ? RT_CELL_BITS_MAX : cell_bits;
     return RT_OK;
 }
 
@@ -1368,8 +1377,8 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
         hipLaunchKernelGGL(k_expand_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, n, src, (uint4*)morton_codes->ptr);
 
     // the library's own hierarchy: same triangles, same kernels, keys without overlapping bits. Only the traversal
-    // kernel that walks it needs it.
-    a->sp_built = dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL && a->sp_tris != nullptr;
+    // kernel that walks it needs it (rt_accel_set_second_hierarchy).
+    a->sp_built = a->want_spatial && a->sp_tris != nullptr;
     if (!a->sp_built) return rt_launch_status();
     uint2* other = src == a->keys_a ? a->keys_b : a->keys_a;
     const SceneBounds spb = make_bounds(scene_min, scene_max);
@@ -1390,8 +1399,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     RT_HIP(hipMemsetAsync(a->cells, 0, (size_t)RT_CELLS_START * sizeof(uint32_t), s));
     hipLaunchKernelGGL(k_cell_hist, dim3(div_up(n, 256u)), dim3(256), 0, s, n, (const uint2*)sp_src, a->cells);
     hipLaunchKernelGGL(k_cell_sums, dim3((1u << RT_CELL_BITS_MAX) / 256u), dim3(256), 0, s, a->cells);
-    static const uint32_t t_cap = std::getenv("GPURT_CELL_BITS") ? (uint32_t)atoi(std::getenv("GPURT_CELL_BITS")) : RT_CELL_BITS_MAX;
-    hipLaunchKernelGGL(k_cell_choose, dim3(1), dim3(1024), 0, s, a->cells, slots_log2, t_cap);
+    hipLaunchKernelGGL(k_cell_choose, dim3(1), dim3(1024), 0, s, a->cells, slots_log2, a->cell_bits_cap);
     hipLaunchKernelGGL(k_cell_starts, dim3(div_up(n, 256u)), dim3(256), 0, s, n, (const uint2*)sp_src, a->cells);
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(slots, 256u)), dim3(256), 0, s, 2u * slots, sl, (const uint32_t*)sp_src,
                        (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, a->sp_pairs, a->sp_quads,

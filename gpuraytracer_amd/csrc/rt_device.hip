@@ -46,6 +46,32 @@ int rt_device_create(int gpu_index, rt_device** out) {
                           : (v && !std::strcmp(v, "simple")) ? RT_TRACE_KERNEL_SIMPLE
                                                              : RT_TRACE_KERNEL_SPATIAL;
     }
+    d->slab_division = false;
+    d->listed_valid = false;
+    {   // tuning of the traversal kernels: defaults, or the environment's values (read here, once per device)
+        auto env = [](const char* name, uint32_t fallback) -> uint32_t {
+            const char* v = std::getenv(name);
+            return (v && *v) ? (uint32_t)std::strtoul(v, nullptr, 10) : fallback;
+        };
+        rt_trace_tuning t;
+        t.leaf_threshold = env("GPURT_LEAF_THRESHOLD", 0u);
+        t.refill_threshold = env("GPURT_REFILL_THRESHOLD", 0u);
+        t.blocks_per_cu = env("GPURT_BLOCKS_PER_CU", 4u);
+        t.sort_rays = env("GPURT_SORT_RAYS", 1u);
+        t.deal_shift = env("GPURT_DEAL_SHIFT", 6u);
+        t.cost_bits = env("GPURT_COST_BITS", 6u);
+        t.cost_depth = env("GPURT_COST_DEPTH", 0u);
+        t.cost_stride = env("GPURT_COST_STRIDE", 0u);
+        t.cost_chord = env("GPURT_COST_CHORD", 2u);
+        t.key_passes = env("GPURT_KEY_PASSES", 0u);
+        d->tuning = rt_clamp_tuning(t);
+    }
+    {
+        hipDeviceProp_t prop;
+        hipError_t pe = hipGetDeviceProperties(&prop, gpu_index);
+        if (pe != hipSuccess) { delete d; return RT_ERR_HIP_BASE + (int)pe; }
+        d->compute_units = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+    }
     d->time_traverse = false;
     d->timing_events = nullptr;
     d->timing_count = d->timing_capacity = 0;

@@ -33,6 +33,10 @@ struct rt_device {
     float* bounds_partials;    // [kBoundsBlocks][6] per-workgroup centroid bounds of the scene-bounds reduction
     // optional event pairs around the traversal kernel (rt_device_set_traverse_timing)
     int trace_kernel;          // RT_TRACE_KERNEL_*: which traversal kernel rt_trace_rays launches
+    bool slab_division;        // rt_device_set_slab_division: the box test divides by the direction, as the reference writes it
+    rt_trace_tuning tuning;    // rt_device_set_trace_tuning (initial values: defaults or GPURT_* environment variables)
+    int compute_units;         // of this GPU: the persistent kernels launch a multiple of it
+    bool listed_valid;         // the last trace call ran the SPATIAL kernel, so queue_counter[128] is its list length
     bool time_traverse;
     hipEvent_t* timing_events;      // [2 * timing_capacity]: start, stop, start, stop, ...
     uint32_t timing_count, timing_capacity;
@@ -61,6 +65,24 @@ static inline int rt_set_device(const rt_device* dev) {
     if (!dev) return RT_ERR_INVALID_ARGUMENT;
     RT_HIP(hipSetDevice(dev->gpu));
     return RT_OK;
+}
+
+// the ranges rt_device_set_trace_tuning accepts
+static inline rt_trace_tuning rt_clamp_tuning(rt_trace_tuning t) {
+    if (t.leaf_threshold > 64u) t.leaf_threshold = 64u;
+    if (t.refill_threshold > 64u) t.refill_threshold = 64u;
+    if (t.blocks_per_cu < 1u) t.blocks_per_cu = 1u;
+    if (t.blocks_per_cu > 8u) t.blocks_per_cu = 8u;
+    t.sort_rays = t.sort_rays ? 1u : 0u;
+    if (t.deal_shift < 6u) t.deal_shift = 6u;
+    if (t.deal_shift > 20u) t.deal_shift = 20u;
+    if (t.cost_bits < 6u) t.cost_bits = 6u;
+    if (t.cost_bits > 12u) t.cost_bits = 12u;
+    if (t.cost_depth == 1u) t.cost_depth = 2u;
+    if (t.cost_depth > 30u) t.cost_depth = 30u;
+    if (t.cost_chord > 2u) t.cost_chord = 2u;
+    if (t.key_passes > 3u) t.key_passes = 3u;
+    return t;
 }
 
 static inline int rt_launch_status() {
@@ -172,7 +194,9 @@ struct rt_accel {
     float4* sp_tris;
     uint32_t* ranks;           // [max_prims]
     uint32_t* cells;           // Morton-cell bookkeeping of the last build: see the offsets below
-    bool sp_built;             // the last build made it (builds on a device set to another traversal kernel do not)
+    bool want_spatial;         // rt_accel_set_second_hierarchy: builds make the library's own hierarchy
+    uint32_t cell_bits_cap;    // ... with leaf slots aligned to Morton cells of at most this many bits
+    bool sp_built;             // the last build made it
     rt_levels sp_lv;           // shape of that hierarchy at the last build: rt_spatial_slots(num_prims) leaves, all levels full
 };
 // rt_accel::cells, in uint32 (everything before RT_CELLS_START is cleared by every build): [0..7] layout {cell bits T, largest cell at T = 21, 18, ... 3}; then the triangles per cell

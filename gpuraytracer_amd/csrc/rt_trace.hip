@@ -77,10 +77,13 @@ __device__ __forceinline__ void check_hit(const Hit& h, float tmin, float tmax, 
     if (use) { best = h; best_ci = ci; }
 }
 
-// shader/CS_TraceRays.hlsl:81-97
+// shader/CS_TraceRays.hlsl:81-97. DIV: inv_d is the direction itself and the test divides by it, as the shader is
+// written; otherwise inv_d holds one reciprocal per axis and the test multiplies.
+template <bool DIV = false>
 __device__ __forceinline__ float slab(f3 o, f3 inv_d, float tmin_r, float tmax_r, float4 lo, float4 hi) {
-    f3 t1 = mul(sub(mk(lo.x, lo.y, lo.z), o), inv_d);
-    f3 t2 = mul(sub(mk(lo.w, hi.x, hi.y), o), inv_d);
+    const f3 a = sub(mk(lo.x, lo.y, lo.z), o), b = sub(mk(lo.w, hi.x, hi.y), o);
+    f3 t1 = DIV ? mk(a.x / inv_d.x, a.y / inv_d.y, a.z / inv_d.z) : mul(a, inv_d);
+    f3 t2 = DIV ? mk(b.x / inv_d.x, b.y / inv_d.y, b.z / inv_d.z) : mul(b, inv_d);
     float tmin = fmaxf(fminf(t1.x, t2.x), fmaxf(fminf(t1.y, t2.y), fminf(t1.z, t2.z)));
     float tmax = fminf(fmaxf(t1.x, t2.x), fminf(fmaxf(t1.y, t2.y), fmaxf(t1.z, t2.z)));
     if ((tmax < tmin) || (tmax <= 0.0f) || (tmax < tmin_r) || (tmin > tmax_r)) tmin = 1e30f;
@@ -184,6 +187,9 @@ __device__ __forceinline__ void shade_ray(const TraceParams& p, const ShadeBuffe
     const uint32_t px = pv >> 16, py = pv & 0xffffu;
     const uint32_t off = __float_as_uint(o1.w);
     const uint32_t idx = local_ray(p, ((uint32_t)p.width * py + px) * p.rpp + off);
+    // pixel data that does not belong to these rows: an out-of-range structured-buffer access of the reference reads
+    // zeros and drops the write; here the ray is left alone
+    if (idx >= p.num_rays) return;
     float4 S = b.scattered[idx];
     float4 E = b.emitted[idx];
 
@@ -304,7 +310,7 @@ __device__ __forceinline__ bool pop_node(uint32_t& k, uint32_t& i, uint32_t root
 }
 
 // ---- simple form: one thread per ray through traversal and shading (also the RT_USE_BVH = 0 path) ----
-template <bool USE_BVH, bool STATS>
+template <bool USE_BVH, bool STATS, bool DIV = false>
 __global__ __launch_bounds__(256) void k_trace(TraceParams p, ShadeBuffers b, const float4* __restrict__ nodes,
                                                unsigned long long* __restrict__ stats) {
     __shared__ uint32_t s_off[33];
@@ -333,17 +339,17 @@ __global__ __launch_bounds__(256) void k_trace(TraceParams p, ShadeBuffers b, co
         }
     } else {
         // shader/CS_TraceRays.hlsl:179-237, walked without a stack
-        const f3 inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+        const f3 inv_d = DIV ? dir : mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
         const uint32_t root_level = p.lv.count - 1u;
         if (STATS) n_nodes++;
         // the trunk is entered on any box hit; every other node also has to start before the best hit
-        if (slab(org, inv_d, tmin_r, tmax_r, nodes[0], nodes[1]) != 1e30f) {
+        if (slab<DIV>(org, inv_d, tmin_r, tmax_r, nodes[0], nodes[1]) != 1e30f) {
             uint32_t k = root_level - 1u, i = 0u;
             for (;;) {
                 if (i < s_n[k]) {
                     const size_t node = (size_t)s_off[k] + i;
                     const float4 lo = nodes[2 * node], hi = nodes[2 * node + 1];
-                    const float bt = slab(org, inv_d, tmin_r, tmax_r, lo, hi);
+                    const float bt = slab<DIV>(org, inv_d, tmin_r, tmax_r, lo, hi);
                     if (STATS) n_nodes++;
                     const bool enter = (bt != 1e30f) && (bt < best.t);
                     if (enter && k > 0u) { k--; i <<= 1; continue; }
@@ -369,12 +375,15 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 // shader/CS_TraceRays.hlsl:81-97 for both boxes of an interleaved sibling pair at once (same operations per
 // box as slab(); the subtractions and multiplications cover the two boxes with one packed instruction each)
+template <bool DIV = false>
 __device__ __forceinline__ void slab_pair(f3 o, f3 inv_d, float tmin_r, float tmax_r, float4 q0, float4 q1, float4 q2, float& bt0,
                                           float& bt1) {
     const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
     const v2f ix = {inv_d.x, inv_d.x}, iy = {inv_d.y, inv_d.y}, iz = {inv_d.z, inv_d.z};
-    const v2f ax = (v2f{q0.x, q0.y} - ox) * ix, ay = (v2f{q0.z, q0.w} - oy) * iy, az = (v2f{q1.x, q1.y} - oz) * iz;
-    const v2f bx = (v2f{q1.z, q1.w} - ox) * ix, by = (v2f{q2.x, q2.y} - oy) * iy, bz = (v2f{q2.z, q2.w} - oz) * iz;
+    v2f ax = v2f{q0.x, q0.y} - ox, ay = v2f{q0.z, q0.w} - oy, az = v2f{q1.x, q1.y} - oz;
+    v2f bx = v2f{q1.z, q1.w} - ox, by = v2f{q2.x, q2.y} - oy, bz = v2f{q2.z, q2.w} - oz;
+    if (DIV) { ax = ax / ix; ay = ay / iy; az = az / iz; bx = bx / ix; by = by / iy; bz = bz / iz; }     // DIV: inv_d is the direction
+    else { ax = ax * ix; ay = ay * iy; az = az * iz; bx = bx * ix; by = by * iy; bz = bz * iz; }
     float tn0 = fmaxf(fminf(ax.x, bx.x), fmaxf(fminf(ay.x, by.x), fminf(az.x, bz.x)));
     float tn1 = fmaxf(fminf(ax.y, bx.y), fmaxf(fminf(ay.y, by.y), fminf(az.y, bz.y)));
     const float tx0 = fminf(fmaxf(ax.x, bx.x), fminf(fmaxf(ay.x, by.x), fmaxf(az.x, bz.x)));
@@ -443,7 +452,7 @@ __device__ __forceinline__ void check_hit_select(bool wanted, const Hit& h, floa
 // is out of date, and entering a noted child without comparing its entry distance again as the reference
 // does, only adds box tests. The counting variant does compare again and walks only while no leaf is waiting,
 // which makes its box tests those of the reference's walk, too.
-template <bool STATS>
+template <bool STATS, bool DIV = false>
 __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* __restrict__ rays, const float4* __restrict__ nodes,
                                                   const float4* __restrict__ pairs, const float4* __restrict__ sorted_tris,
                                                   float4* __restrict__ hit_records, uint32_t* __restrict__ hit_ci,
@@ -505,12 +514,12 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
                         const float4 r0 = rays[2 * (size_t)rid], r1 = rays[2 * (size_t)rid + 1];
                         org = mk(r0.x, r0.y, r0.z); dir = mk(r0.w, r1.x, r1.y);
                         tmin_r = r1.z; tmax_r = r1.w;
-                        inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                        inv_d = DIV ? dir : mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
                         best.t = tmax_r; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
                         best_ci = 0u;
                         if (STATS) { n_nodes++; n_rays++; }
                         // the trunk is entered on any box hit
-                        if (slab(org, inv_d, tmin_r, tmax_r, root_lo, root_hi) != 1e30f) {
+                        if (slab<DIV>(org, inv_d, tmin_r, tmax_r, root_lo, root_hi) != 1e30f) {
                             ray = rid; h = 1u;
                             walk_done = false; popping = false; noted = 0u;
                         } else {
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
             const float4* rec = pairs + 4 * (size_t)h;
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
             float bt0, bt1;
-            slab_pair(org, inv_d, tmin_r, tmax_r, q0, q1, q2, bt0, bt1);
+            slab_pair<DIV>(org, inv_d, tmin_r, tmax_r, q0, q1, q2, bt0, bt1);
             const bool valid1 = q0.y == q0.y;                      // a missing child is stored as NaNs
             if (STATS) n_nodes += valid1 ? 2u : 1u;
             const bool hit0 = (bt0 != 1e30f) && (bt0 < best.t);
@@ -1315,12 +1324,6 @@ int convert_workspace(rt_device* dev, uint32_t num_prims, const rt_levels& lv) {
     return RT_OK;
 }
 
-uint32_t env_u32(const char* name, uint32_t fallback) {
-    const char* v = std::getenv(name);
-    if (!v || !*v) return fallback;
-    return (uint32_t)std::strtoul(v, nullptr, 10);
-}
-
 int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, const rt_accel* accel, const rt_buffer* indices,
                  const rt_buffer* vertices, const rt_buffer* materials, const rt_buffer* texture_ids,
                  const rt_buffer* texture_atlas, uint32_t atlas_elements, rt_buffer* rays, rt_buffer* old_rays,
@@ -1337,7 +1340,13 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     const uint32_t row_stride = rows ? rows->row_stride : 1u;
     const uint64_t first_ray = rows ? (uint64_t)rows->first_row * row_len : 0u;
     if (!row_stride || row_len > 0xffffffffull || first_ray > 0xffffffffull) return RT_ERR_INVALID_ARGUMENT;
-    if (rows && (uint64_t)rows->num_rows * row_len != nr) return RT_ERR_INVALID_ARGUMENT;
+    if (info->screen_dimensions[1] <= 0) return RT_ERR_INVALID_ARGUMENT;
+    if (rows) {
+        if (!rt_rows_fit(rows->first_row, rows->num_rows, rows->row_stride, (uint32_t)info->screen_dimensions[1])) return RT_ERR_INVALID_ARGUMENT;
+        if ((uint64_t)rows->num_rows * row_len != nr) return RT_ERR_INVALID_ARGUMENT;
+    } else if ((uint64_t)info->screen_dimensions[1] * row_len != nr) {
+        return RT_ERR_INVALID_ARGUMENT;
+    }
     if (rays->bytes < (size_t)nr * 32u || old_rays->bytes < (size_t)nr * 32u || ray_pixels->bytes < (size_t)nr * 4u ||
         scattered_light->bytes < (size_t)nr * 16u || emitted_light->bytes < (size_t)nr * 16u)
         return RT_ERR_BUFFER_TOO_SMALL;
@@ -1347,16 +1356,18 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     int rc = rt_set_device(dev);
     if (rc) return rc;
 
-    // the traversal kernel is a device setting (rt_device_set_trace_kernel); the other knobs are read once
+    // the traversal kernel and its tuning are device settings (rt_device_set_trace_kernel, rt_device_set_trace_tuning)
+    const rt_trace_tuning& tune = dev->tuning;
+    const bool divide = dev->slab_division;
     const bool simple_kernel = dev->trace_kernel == RT_TRACE_KERNEL_SIMPLE;
-    const bool spatial_kernel = dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL && accel && accel->sp_built;
-    const bool quad_kernel = dev->trace_kernel == RT_TRACE_KERNEL_QUAD || dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL;
+    const bool spatial_kernel = !divide && dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL && accel && accel->sp_built;
+    const bool quad_kernel = !divide && (dev->trace_kernel == RT_TRACE_KERNEL_QUAD || dev->trace_kernel == RT_TRACE_KERNEL_SPATIAL);
     // (lanes with a leaf waiting that start a triangle round: the walk on the library's own hierarchy meets few
     // leaves and does better with fuller rounds)
-    static const uint32_t leaf_threshold_env = env_u32("GPURT_LEAF_THRESHOLD", 0u);
-    const uint32_t leaf_threshold = leaf_threshold_env ? leaf_threshold_env : (spatial_kernel ? 32u : 16u);
-    static const uint32_t blocks_per_cu = env_u32("GPURT_BLOCKS_PER_CU", 4u);
-    static const uint32_t sort_rays = env_u32("GPURT_SORT_RAYS", 1u);
+    const uint32_t leaf_threshold = tune.leaf_threshold ? tune.leaf_threshold : (spatial_kernel ? 32u : 16u);
+    const uint32_t blocks_per_cu = tune.blocks_per_cu;
+    const uint32_t sort_rays = tune.sort_rays;
+    dev->listed_valid = false;
 
     TraceParams p;
     p.width = info->screen_dimensions[0];
@@ -1372,13 +1383,10 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     p.num_materials = (uint32_t)(materials->bytes / sizeof(rt_pbr_material));
     p.num_textures = (uint32_t)(texture_ids->bytes / sizeof(rt_texture_id));
     p.leaf_threshold = leaf_threshold < 1u ? 1u : (leaf_threshold > 64u ? 64u : leaf_threshold);
-    static const uint32_t deal_shift_env = env_u32("GPURT_DEAL_SHIFT", 6u);
-    static const uint32_t cost_bits = env_u32("GPURT_COST_BITS", 6u) < 6u ? 6u : (env_u32("GPURT_COST_BITS", 6u) > 12u ? 12u : env_u32("GPURT_COST_BITS", 6u));
+    const uint32_t cost_bits = tune.cost_bits;
     // (free lanes that start a refill: taking rays from the spatial kernel's stock is cheap, a refill of the others is not)
-    static const uint32_t refill_threshold_env = env_u32("GPURT_REFILL_THRESHOLD", 0u);
-    const uint32_t refill_threshold = refill_threshold_env ? refill_threshold_env : (spatial_kernel ? 8u : 16u);
-    p.refill_threshold = refill_threshold > 64u ? 64u : refill_threshold;
-    p.deal_shift = deal_shift_env < 6u ? 6u : (deal_shift_env > 20u ? 20u : deal_shift_env);
+    p.refill_threshold = tune.refill_threshold ? tune.refill_threshold : (spatial_kernel ? 8u : 16u);
+    p.deal_shift = tune.deal_shift;
     const uint32_t deal_block = 1u << p.deal_shift;
     p.queue_chunk = ((((nr + deal_block - 1u) / deal_block) + 7u) / 8u) * deal_block;      // whole blocks, dealt to the eight queues in turn
     p.lv.count = 0;
@@ -1409,8 +1417,13 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         return rt_launch_status();
     }
     if (simple_kernel) {
-        if (stats) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, s, p, b, nodes, stats);
-        else hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, s, p, b, nodes, stats);
+        if (divide) {
+            if (stats) hipLaunchKernelGGL((k_trace<true, true, true>), grid, block, 0, s, p, b, nodes, stats);
+            else hipLaunchKernelGGL((k_trace<true, false, true>), grid, block, 0, s, p, b, nodes, stats);
+        } else {
+            if (stats) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, s, p, b, nodes, stats);
+            else hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, s, p, b, nodes, stats);
+        }
         return rt_launch_status();
     }
 
@@ -1418,10 +1431,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     if (rc) return rc;
     RT_HIP(hipMemsetAsync(dev->queue_counter, 0, 1024, s));
     // persistent grid: enough workgroups to fill every CU, never more than there are rays to hand out
-    hipDeviceProp_t prop;
-    static int cus = 0;
-    if (!cus) { RT_HIP(hipGetDeviceProperties(&prop, dev->gpu)); cus = prop.multiProcessorCount; }
-    uint32_t groups = (uint32_t)cus * (blocks_per_cu ? blocks_per_cu : 1u);
+    uint32_t groups = (uint32_t)dev->compute_units * blocks_per_cu;
     if (groups > grid.x) groups = grid.x;
     const float4* ray_in = (const float4*)rays->ptr;
     // the walk runs on the private copy of the hierarchy; a call without an accel gets one made from its buffers
@@ -1450,19 +1460,16 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         const bool on_spatial = spatial_kernel && !stats;
         const rt_levels& kl = on_spatial ? accel->sp_lv : p.lv;
         const uint32_t root_level = kl.count - 1u;
-        static const uint32_t probe_depth_env = env_u32("GPURT_COST_DEPTH", 0u);
+        const uint32_t probe_depth_env = tune.cost_depth;
         const uint32_t probe_depth = probe_depth_env >= 2u ? probe_depth_env : (on_spatial ? 5u : 10u);
         const uint32_t depth = root_level > probe_depth ? probe_depth : (root_level > 1u ? root_level - 1u : 1u);
-        // (... and better still, and nearly free: the length of the ray's way through the trunk's box; GPURT_COST_CHORD=0
-        // or a GPURT_COST_DEPTH bring the probe back)
-        static const uint32_t chord_env = env_u32("GPURT_COST_CHORD", 2u);
-        const bool chord_only = chord_env == 2u ? (on_spatial && probe_depth_env < 2u) : chord_env != 0u;
+        // (... and better still, and nearly free: the length of the ray's way through the trunk's box; cost_chord = 0
+        // or a cost_depth bring the probe back)
+        const bool chord_only = tune.cost_chord == 2u ? (on_spatial && probe_depth_env < 2u) : tune.cost_chord != 0u;
         const uint32_t nodes_there = chord_only ? 0u : kl.n[root_level - depth];
-        static const uint32_t probe_stride_env = env_u32("GPURT_COST_STRIDE", 0u);
-        const uint32_t probe_stride = probe_stride_env ? probe_stride_env : (on_spatial ? 1u : 4u);
+        const uint32_t probe_stride = tune.cost_stride ? tune.cost_stride : (on_spatial ? 1u : 4u);
         // sorting passes = bytes of the key that count (the class, then as much of the locality part as fits)
-        static const uint32_t key_passes_env = env_u32("GPURT_KEY_PASSES", 0u);
-        const uint32_t key_passes = key_passes_env < 1u ? (on_spatial ? 2u : 3u) : (key_passes_env > 3u ? 3u : key_passes_env);
+        const uint32_t key_passes = tune.key_passes < 1u ? (on_spatial ? 2u : 3u) : tune.key_passes;
         uint32_t cost_shift = 0u;
         while (((nodes_there / probe_stride) >> cost_shift) > (1u << cost_bits) - 1u) cost_shift++;
         key_nodes = on_spatial ? (const float4*)accel->sp_nodes : nodes;
@@ -1474,8 +1481,8 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     }
     // waiting leaves; the counting variant also keeps the entry distances of noted children, one row per depth
     const size_t lds_bytes = ((size_t)kFifo * 512u + (stats ? (size_t)p.lv.count * 256u : 0u)) * sizeof(uint32_t);
-#define RT_LAUNCH_TRAVERSE(STATS)                                                                                             \
-    hipLaunchKernelGGL((k_traverse<STATS>), dim3(groups), block, lds_bytes, s, p, ray_in, nodes, pairs, st, dev->hit_records, \
+#define RT_LAUNCH_TRAVERSE(STATS, DIV)                                                                                         \
+    hipLaunchKernelGGL((k_traverse<STATS, DIV>), dim3(groups), block, lds_bytes, s, p, ray_in, nodes, pairs, st, dev->hit_records, \
                        dev->hit_ci, dev->queue_counter, order, stats)
     hipEvent_t* timing = nullptr;
     if (dev->time_traverse) {
@@ -1489,15 +1496,18 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
             dev->timing_events = ev;
             dev->timing_capacity = cap;
         }
-        timing = dev->timing_events + 2u * dev->timing_count++;
+        timing = dev->timing_events + 2u * dev->timing_count;
         RT_HIP(hipEventRecord(timing[0], s));
     }
     // k_traverse_quad addresses its records and the leaves with 32-bit byte offsets
     const bool offsets_fit = rt_aligned_node_slots(&p.lv) * sizeof(rt_aabb) <= 0xffffffffull && (size_t)p.lv.n[0] * 128u <= 0xffffffffull;
-    if (stats) RT_LAUNCH_TRAVERSE(true);
+    if (stats && divide) RT_LAUNCH_TRAVERSE(true, true);
+    else if (stats) RT_LAUNCH_TRAVERSE(true, false);
+    else if (divide) RT_LAUNCH_TRAVERSE(false, true);
     else if (spatial_kernel && offsets_fit && p.lv.count >= 3u && accel->sp_lv.n[0] <= RT_SPATIAL_SLOTS_MAX) {
         // first the walk on the library's own hierarchy, then the reference's walk for the rays it has listed
         uint32_t* listed = dev->queue_counter + 128;
+        dev->listed_valid = true;
         TraceParams ps = p;
         ps.lv = accel->sp_lv;
 #define RT_LAUNCH_SPATIAL(COUNT)                                                                                              \
@@ -1515,9 +1525,12 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     } else if (quad_kernel && offsets_fit && p.lv.count >= 3u && quads)
         hipLaunchKernelGGL(k_traverse_quad, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in, nodes, pairs, quads,
                            st, dev->hit_records, dev->hit_ci, dev->queue_counter, order, (const uint32_t*)nullptr);
-    else RT_LAUNCH_TRAVERSE(false);
+    else RT_LAUNCH_TRAVERSE(false, false);
 #undef RT_LAUNCH_TRAVERSE
-    if (timing) RT_HIP(hipEventRecord(timing[1], s));
+    if (timing) {
+        RT_HIP(hipEventRecord(timing[1], s));
+        dev->timing_count++;          // only a complete pair counts
+    }
     rc = rt_launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(k_shade, grid, block, 0, s, p, b, (const float4*)dev->hit_records, (const uint32_t*)dev->hit_ci);
@@ -1543,6 +1556,24 @@ int rt_device_set_walk_stats(rt_device* dev, rt_buffer* stats) {
 int rt_device_set_trace_kernel(rt_device* dev, int kernel) {
     if (!dev || kernel < RT_TRACE_KERNEL_QUAD || kernel > RT_TRACE_KERNEL_SPATIAL) return RT_ERR_INVALID_ARGUMENT;
     dev->trace_kernel = kernel;
+    return RT_OK;
+}
+
+int rt_device_set_slab_division(rt_device* dev, int enable) {
+    if (!dev) return RT_ERR_INVALID_ARGUMENT;
+    dev->slab_division = enable != 0;
+    return RT_OK;
+}
+
+int rt_device_get_trace_tuning(rt_device* dev, rt_trace_tuning* out) {
+    if (!dev || !out) return RT_ERR_INVALID_ARGUMENT;
+    *out = dev->tuning;
+    return RT_OK;
+}
+
+int rt_device_set_trace_tuning(rt_device* dev, const rt_trace_tuning* tuning) {
+    if (!dev || !tuning) return RT_ERR_INVALID_ARGUMENT;
+    dev->tuning = rt_clamp_tuning(*tuning);
     return RT_OK;
 }
 
@@ -1573,7 +1604,7 @@ int rt_device_traverse_timing(rt_device* dev, double* total_ms, uint32_t* launch
 int rt_device_listed_rays(rt_device* dev, uint32_t* count) {
     if (!dev || !count) return RT_ERR_INVALID_ARGUMENT;
     *count = 0u;
-    if (!dev->queue_counter) return RT_OK;        // nothing traced yet
+    if (!dev->queue_counter || !dev->listed_valid) return RT_OK;        // nothing traced yet, or not by the SPATIAL kernel
     int rc = rt_set_device(dev);
     if (rc) return rc;
     RT_HIP(hipMemcpyAsync(count, dev->queue_counter + 128, sizeof(uint32_t), hipMemcpyDeviceToHost, dev->stream));

@@ -88,13 +88,6 @@ uint64_t rth_build_atlas(const MeshInfo* m, const char* directory_prefix, uint8_
 		std::string path = std::string(directory_prefix ? directory_prefix : "") + m->TextureNames[i];
 		if (!atlas.AddTexture(&id, LoadTextureFromFile(path))) return 0;
 	}
-	if (m->TextureNameCount <= 1)
-	{
-		//no texture: Initialize() would add the default slot; build it through a throw-away AddTexture failure path instead
-		TextureInfo none{};
-		uint32_t id = 0;
-		atlas.AddTexture(&id, none);
-	}
 	std::vector<uint8_t> bytes;
 	std::vector<TextureID> tids;
 	atlas.BuildHostImage(bytes, tids);
@@ -151,5 +144,7 @@ void rth_pipeline_destroy(RaytracerPipeline* p) { delete p; }
 
 int rth_write_ppm(const char* path, const float* pixels, uint32_t w, uint32_t h) { return WriteImagePPM(path, pixels, w, h) ? 1 : 0; }
 int rth_write_pfm(const char* path, const float* pixels, uint32_t w, uint32_t h) { return WriteImagePFM(path, pixels, w, h) ? 1 : 0; }
+int rth_write_png(const char* path, const float* pixels, uint32_t w, uint32_t h) { return WriteImagePNG(path, pixels, w, h) ? 1 : 0; }
+uint32_t rth_encode_srgb8(float linear) { return EncodeSRGB8(linear); }
 
 }  // extern "C"

@@ -4,7 +4,7 @@
 //
 //   rt_headless [--scene file.obj | --synthetic N] [--width W] [--height H] [--rpp R] [--depth D]
 //               [--cycles C] [--no-bvh] [--per-shader-build] [--rebuild] [--camera px py pz fx fy fz]
-//               [--seed S] [--gpu G] [--out image.ppm] [--pfm image.pfm] [--dynamic] [--reference-walk]
+//               [--seed S] [--gpu G] [--out image.ppm|image.png] [--pfm image.pfm] [--dynamic] [--reference-walk]
 //               [--resume state.bin] [--save-state state.bin]
 
 #include <chrono>
@@ -106,7 +106,9 @@ int main(int argc, char** argv)
 	if (!sSaveState.empty() && !rtRenderer.SaveState(sSaveState)) { std::cout << "Error while writing " << sSaveState << "\n"; return 1; }
 	std::vector<float> stdPixels((size_t)rtSettings.WindowWidth * rtSettings.WindowHeight * 4);
 	if (!rtRenderer.ReadOutput(stdPixels.data())) { std::cout << "Error while reading the image\n"; return 1; }
-	if (!sOut.empty() && !WriteImagePPM(sOut, stdPixels.data(), rtSettings.WindowWidth, rtSettings.WindowHeight)) { std::cout << "Error while writing " << sOut << "\n"; return 1; }
+	const bool bPNG = sOut.size() > 4 && sOut.compare(sOut.size() - 4, 4, ".png") == 0;
+	if (!sOut.empty() && !(bPNG ? WriteImagePNG(sOut, stdPixels.data(), rtSettings.WindowWidth, rtSettings.WindowHeight)
+	                              : WriteImagePPM(sOut, stdPixels.data(), rtSettings.WindowWidth, rtSettings.WindowHeight))) { std::cout << "Error while writing " << sOut << "\n"; return 1; }
 	if (!sPFM.empty() && !WriteImagePFM(sPFM, stdPixels.data(), rtSettings.WindowWidth, rtSettings.WindowHeight)) { std::cout << "Error while writing " << sPFM << "\n"; return 1; }
 	return 0;
 }

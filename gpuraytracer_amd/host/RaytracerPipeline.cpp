@@ -9,7 +9,10 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <sstream>
 #include <vector>
+
+#include <zlib.h>
 
 namespace RT::GraphicsAPI
 {
@@ -244,7 +247,8 @@ namespace RT::GraphicsAPI
 		m_iNumPrimitives(0),
 		m_rtBVHInfoData(),
 		m_rtBVHBuffer(nullptr),
-		m_rtAccel(nullptr)
+		m_rtAccel(nullptr),
+		m_bSecondHierarchy(true)
 	{
 	}
 
@@ -298,12 +302,24 @@ namespace RT::GraphicsAPI
 		return rt_bvh_build(m_rtDevice, &m_rtBVHInfoData, m_rtBVHBuffer) == RT_OK;
 	}
 
+	bool BuildBVH::CreateAccel()
+	{
+		if (rt_accel_create(m_rtDevice, m_iNumPrimitives, &m_rtAccel) != RT_OK) return false;
+		return rt_accel_set_second_hierarchy(m_rtAccel, m_bSecondHierarchy ? 1 : 0, 0xffffffffu) == RT_OK;
+	}
+
+	void BuildBVH::SetSecondHierarchy(bool bEnable)
+	{
+		m_bSecondHierarchy = bEnable;
+		if (m_rtAccel) rt_accel_set_second_hierarchy(m_rtAccel, bEnable ? 1 : 0, 0xffffffffu);
+	}
+
 	bool BuildBVH::BuildFusedMoved(RaytracerMesh* rtMesh, rt_buffer* rtBounds, rt_buffer* rtMortonCodes)
 	{
 		const rt_buffer* rtIndices = nullptr;
 		const rt_buffer* rtVertices = nullptr;
 		rtMesh->Bind(&rtIndices, &rtVertices);
-		if (!m_rtAccel && rt_accel_create(m_rtDevice, m_iNumPrimitives, &m_rtAccel) != RT_OK) return false;
+		if (!m_rtAccel && !CreateAccel()) return false;
 		if (rt_accel_pack_bounds(m_rtAccel, m_iNumPrimitives, rtIndices, rtVertices, rtBounds) != RT_OK) return false;
 		return rt_accel_build_device_bounds(m_rtAccel, rtBounds, m_rtBVHBuffer, rtMortonCodes) == RT_OK;
 	}
@@ -315,7 +331,7 @@ namespace RT::GraphicsAPI
 			const rt_buffer* rtIndices = nullptr;
 			const rt_buffer* rtVertices = nullptr;
 			rtMesh->Bind(&rtIndices, &rtVertices);
-			if (rt_accel_create(m_rtDevice, m_iNumPrimitives, &m_rtAccel) != RT_OK) return false;
+			if (!CreateAccel()) return false;
 			if (rt_accel_pack(m_rtAccel, m_iNumPrimitives, rtIndices, rtVertices) != RT_OK) return false;
 		}
 		const float pMin[3] = { rtSceneAABB.Min.x, rtSceneAABB.Min.y, rtSceneAABB.Min.z };
@@ -537,6 +553,7 @@ namespace RT::GraphicsAPI
 			if (!(m_rtSortPrimitives->Initialize(m_rtDevice, iNumPrimitives, rtMeshData.SceneAABB))) return false;
 			m_rtBuildBVH = new BuildBVH();
 			if (!(m_rtBuildBVH->Initialize(m_rtDevice, iNumPrimitives))) return false;
+			m_rtBuildBVH->SetSecondHierarchy(!m_rtSettings.ReferenceOrderWalk);
 		}
 
 		m_rtTraceRays = new TraceRays();
@@ -615,7 +632,8 @@ namespace RT::GraphicsAPI
 		return rt_buffer_readback(m_rtUAVDescriptorHeap->Slots[6], pPixels, iBytes, 0) == RT_OK;
 	}
 
-	//file: "GPURTSTATE1 <width> <height> <samples>\n" followed by width * height float4 (little-endian binary32)
+	//file: "GPURTSTATE2 <width> <height> <samples> <frame>\n", the two generators' states as std::mt19937 writes them
+	//(one line each: ray generation, tracing), then width * height float4 (little-endian binary32)
 	bool RaytracerPipeline::SaveState(const std::string& sFileName)
 	{
 		if (m_iIteration != 0) return false;		//only between two sample cycles
@@ -624,7 +642,9 @@ namespace RT::GraphicsAPI
 		if (!ReadResult(stdPixels.data())) return false;
 		std::ofstream stdFile(sFileName, std::ios::binary);
 		if (!stdFile) return false;
-		stdFile << "GPURTSTATE1 " << m_rtSettings.WindowWidth << " " << m_rtSettings.WindowHeight << " " << m_rtImageGeneration->GetNumSamples() << "\n";
+		stdFile << "GPURTSTATE2 " << m_rtSettings.WindowWidth << " " << m_rtSettings.WindowHeight << " " << m_rtImageGeneration->GetNumSamples()
+			<< " " << m_iFrame << "\n";
+		stdFile << m_rtCameraRayGen->GetPRNG() << "\n" << m_rtTraceRays->GetPRNG() << "\n";
 		stdFile.write((const char*)stdPixels.data(), (std::streamsize)(stdPixels.size() * sizeof(float)));
 		return (bool)stdFile;
 	}
@@ -635,15 +655,22 @@ namespace RT::GraphicsAPI
 		std::ifstream stdFile(sFileName, std::ios::binary);
 		if (!stdFile) return false;
 		std::string sMagic;
-		uint32_t iWidth = 0, iHeight = 0, iSamples = 0;
-		stdFile >> sMagic >> iWidth >> iHeight >> iSamples;
-		if (!stdFile || sMagic != "GPURTSTATE1" || stdFile.get() != '\n') return false;
+		uint32_t iWidth = 0, iHeight = 0, iSamples = 0, iFrame = 0;
+		stdFile >> sMagic >> iWidth >> iHeight >> iSamples >> iFrame;
+		if (!stdFile || sMagic != "GPURTSTATE2" || stdFile.get() != '\n') return false;
 		if (iWidth != m_rtSettings.WindowWidth || iHeight != m_rtSettings.WindowHeight || iSamples == 0) return false;
+		std::mt19937 stdRayGenPRNG, stdTracePRNG;
+		stdFile >> stdRayGenPRNG >> stdTracePRNG;
+		if (!stdFile || stdFile.get() != '\n') return false;
 		std::vector<float> stdPixels((size_t)iWidth * iHeight * 4);
 		stdFile.read((char*)stdPixels.data(), (std::streamsize)(stdPixels.size() * sizeof(float)));
 		if (stdFile.gcount() != (std::streamsize)(stdPixels.size() * sizeof(float))) return false;
 		if (rt_buffer_upload(m_rtImageGeneration->GetResultBuffer(), stdPixels.data(), stdPixels.size() * sizeof(float), 0) != RT_OK) return false;
 		m_rtImageGeneration->SetNumSamples(iSamples);
+		m_rtCameraRayGen->GetPRNG() = stdRayGenPRNG;
+		m_rtTraceRays->GetPRNG() = stdTracePRNG;
+		m_iFrame = iFrame;
+		//a moving scene is rebuilt at the restored frame before the next cycle's rays (RebuildBVHEveryCycle is on for it)
 		return true;
 	}
 
@@ -655,7 +682,7 @@ namespace RT::GraphicsAPI
 
 
 	//linear -> sRGB encoding of the 8-bit sRGB back buffer the reference presents to
-	static uint8_t EncodeSRGB(float fLinear)
+	uint8_t EncodeSRGB8(float fLinear)
 	{
 		if (!(fLinear > 0.0f)) return 0;
 		if (fLinear >= 1.0f) return 255;
@@ -672,9 +699,53 @@ namespace RT::GraphicsAPI
 		for (uint32_t y = 0; y < iHeight; y++)
 		{
 			for (uint32_t x = 0; x < iWidth; x++)
-				for (int c = 0; c < 3; c++) stdRow[3 * x + c] = EncodeSRGB(pPixels[4 * ((size_t)y * iWidth + x) + c]);
+				for (int c = 0; c < 3; c++) stdRow[3 * x + c] = EncodeSRGB8(pPixels[4 * ((size_t)y * iWidth + x) + c]);
 			stdFile.write((const char*)stdRow.data(), (std::streamsize)stdRow.size());
 		}
+		return (bool)stdFile;
+	}
+
+	//8-bit RGB PNG (colour type 2, no interlace, filter 0 on every row, one zlib stream in one IDAT chunk)
+	bool WriteImagePNG(const std::string& sFileName, const float* pPixels, uint32_t iWidth, uint32_t iHeight)
+	{
+		if (iWidth == 0 || iHeight == 0) return false;
+		std::vector<uint8_t> stdRaw(((size_t)iWidth * 3 + 1) * iHeight);
+		for (uint32_t y = 0; y < iHeight; y++)
+		{
+			uint8_t* pRow = stdRaw.data() + ((size_t)iWidth * 3 + 1) * y;
+			pRow[0] = 0;
+			for (uint32_t x = 0; x < iWidth; x++)
+				for (int c = 0; c < 3; c++) pRow[1 + 3 * x + c] = EncodeSRGB8(pPixels[4 * ((size_t)y * iWidth + x) + c]);
+		}
+		uLongf iPackedSize = compressBound((uLong)stdRaw.size());
+		std::vector<uint8_t> stdPacked(iPackedSize);
+		if (compress2(stdPacked.data(), &iPackedSize, stdRaw.data(), (uLong)stdRaw.size(), 6) != Z_OK) return false;
+
+		std::ofstream stdFile(sFileName, std::ios::binary);
+		if (!stdFile) return false;
+		auto Big = [](uint8_t* p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; };
+		auto Chunk = [&](const char* sType, const uint8_t* pData, uint32_t iSize)
+		{
+			uint8_t pWord[4];
+			Big(pWord, iSize);
+			stdFile.write((const char*)pWord, 4);
+			stdFile.write(sType, 4);
+			if (iSize) stdFile.write((const char*)pData, iSize);
+			uLong iCRC = crc32(0L, (const Bytef*)sType, 4);
+			if (iSize) iCRC = crc32(iCRC, pData, iSize);
+			Big(pWord, (uint32_t)iCRC);
+			stdFile.write((const char*)pWord, 4);
+		};
+		const uint8_t pSignature[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+		stdFile.write((const char*)pSignature, 8);
+		uint8_t pHeader[13];
+		Big(pHeader, iWidth); Big(pHeader + 4, iHeight);
+		pHeader[8] = 8; pHeader[9] = 2; pHeader[10] = 0; pHeader[11] = 0; pHeader[12] = 0;
+		Chunk("IHDR", pHeader, 13);
+		const uint8_t iIntent = 0;		//sRGB chunk: the samples are sRGB-encoded, perceptual intent
+		Chunk("sRGB", &iIntent, 1);
+		Chunk("IDAT", stdPacked.data(), (uint32_t)iPackedSize);
+		Chunk("IEND", nullptr, 0);
 		return (bool)stdFile;
 	}
 

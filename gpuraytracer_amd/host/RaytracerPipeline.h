@@ -68,6 +68,8 @@ namespace RT::GraphicsAPI
 		bool Render();
 
 		const CameraRayGenInfo& GetInfo() const { return m_rtInfoData; };
+		//the host generator the three seeds of every generation are drawn from (checkpoint / resume)
+		std::mt19937& GetPRNG() { return m_stdPRNG; };
 	};
 
 
@@ -103,6 +105,9 @@ namespace RT::GraphicsAPI
 		BVHInfo m_rtBVHInfoData;
 		rt_buffer* m_rtBVHBuffer;
 		rt_accel* m_rtAccel;
+		bool m_bSecondHierarchy;
+
+		bool CreateAccel();
 
 	public:
 		BuildBVH();
@@ -116,6 +121,10 @@ namespace RT::GraphicsAPI
 		//the same for a mesh that has moved on the device: gathers the triangles again, leaves their centroid bounds
 		//(8 floats) in rtBounds and builds with them, without a round trip to the host
 		bool BuildFusedMoved(RaytracerMesh* rtMesh, rt_buffer* rtBounds, rt_buffer* rtMortonCodes);
+
+		//whether the fused builds also make the library's own hierarchy (the default traversal walks it); off for a
+		//pipeline that traces in the reference's order, which never reads it
+		void SetSecondHierarchy(bool bEnable);
 
 		rt_buffer* GetBVH() { return m_rtBVHBuffer; };
 		rt_accel* GetAccel() { return m_rtAccel; };
@@ -146,6 +155,7 @@ namespace RT::GraphicsAPI
 		bool Render(rt_buffer* rtBVH, rt_accel* rtAccel = nullptr);
 
 		RaytracerMesh* GetMesh() { return m_rtMesh; };
+		std::mt19937& GetPRNG() { return m_stdPRNG; };
 	};
 
 
@@ -203,8 +213,9 @@ namespace RT::GraphicsAPI
 		//headless output instead of the window: the tone-mapped image and the accumulated mean, Width * Height float4 each
 		bool ReadOutput(float* pPixels);
 		bool ReadResult(float* pPixels);
-		//checkpoint of the accumulation (the reference has none: its state lives in ResultBuffer and NumSamples only):
-		//the running-mean image and the sample counter, written / restored between two sample cycles
+		//checkpoint of the accumulation (the reference has none: its state lives in ResultBuffer, NumSamples and its two
+		//host generators): the running-mean image, the sample counter, both std::mt19937 states and the frame of a moving
+		//scene, written / restored between two sample cycles, so that k cycles + resume + k cycles = 2k cycles
 		bool SaveState(const std::string& sFileName);
 		bool LoadState(const std::string& sFileName);
 		uint32_t GetNumSamples() const { return m_rtImageGeneration ? m_rtImageGeneration->GetNumSamples() : 0; };
@@ -215,7 +226,10 @@ namespace RT::GraphicsAPI
 		const Settings& GetSettings() const { return m_rtSettings; };
 	};
 
-	//headless writers: 8-bit sRGB PPM of a tone-mapped float4 image, and a little-endian RGB PFM
+	//headless writers: 8-bit sRGB PPM / PNG of a tone-mapped float4 image (the encoding of the R8G8B8A8_UNORM_SRGB back
+	//buffer the reference presents to, src/RenderTarget.cpp:66 of the reference), and a little-endian RGB PFM
+	uint8_t EncodeSRGB8(float fLinear);
 	bool WriteImagePPM(const std::string& sFileName, const float* pPixels, uint32_t iWidth, uint32_t iHeight);
+	bool WriteImagePNG(const std::string& sFileName, const float* pPixels, uint32_t iWidth, uint32_t iHeight);
 	bool WriteImagePFM(const std::string& sFileName, const float* pPixels, uint32_t iWidth, uint32_t iHeight);
 }

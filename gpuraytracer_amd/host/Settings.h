@@ -1,8 +1,9 @@
 #pragma once
 // Compile-time defaults under the reference's macro names (src/Settings.h:4-35 of the reference) and a
 // run-time copy of them, so that one binary can run every benchmark configuration.
-// The reference's macros carry stray semicolons and brace initialisers that only work in the
-// declarations they were written for; the values are the same here, the form is plain.
+// The reference's macros carry stray semicolons that only work in the declarations they were written for;
+// the names and values are the same here, the semicolons are gone. RT_CAMERA_POSITION, RT_CAMERA_FOCUS_POINT and
+// RT_CAMERA_UP_DIRECTION keep the reference's brace-initialiser form (src/Settings.h:28-30 of the reference).
 
 #include <cstdint>
 #include <string>
@@ -27,15 +28,9 @@
 #define RT_CAMERA_FARZ 10000.0f
 
 //for testscene1.obj (for testscene2.obj: position 0,0,0 focus 1,0,0; for testobject4_2.obj: position -2.5,5,-2)
-#define RT_CAMERA_POSITION_X -4.0259f
-#define RT_CAMERA_POSITION_Y 2.1676f
-#define RT_CAMERA_POSITION_Z -2.9459f
-#define RT_CAMERA_FOCUS_POINT_X 0.0f
-#define RT_CAMERA_FOCUS_POINT_Y 0.0f
-#define RT_CAMERA_FOCUS_POINT_Z 0.0f
-#define RT_CAMERA_UP_DIRECTION_X 0.0f
-#define RT_CAMERA_UP_DIRECTION_Y 1.0f
-#define RT_CAMERA_UP_DIRECTION_Z 0.0f
+#define RT_CAMERA_POSITION { -4.0259f, 2.1676f, -2.9459f }
+#define RT_CAMERA_FOCUS_POINT { 0.0f, 0.0f, 0.0f }
+#define RT_CAMERA_UP_DIRECTION { 0.0f, 1.0f, 0.0f }
 
 namespace RT
 {
@@ -53,9 +48,9 @@ namespace RT
 		float CameraFOV = RT_CAMERA_FOV;
 		float CameraNearZ = RT_CAMERA_NEARZ;
 		float CameraFarZ = RT_CAMERA_FARZ;
-		float CameraPosition[3] = { RT_CAMERA_POSITION_X, RT_CAMERA_POSITION_Y, RT_CAMERA_POSITION_Z };
-		float CameraFocusPoint[3] = { RT_CAMERA_FOCUS_POINT_X, RT_CAMERA_FOCUS_POINT_Y, RT_CAMERA_FOCUS_POINT_Z };
-		float CameraUpDirection[3] = { RT_CAMERA_UP_DIRECTION_X, RT_CAMERA_UP_DIRECTION_Y, RT_CAMERA_UP_DIRECTION_Z };
+		float CameraPosition[3] = RT_CAMERA_POSITION;
+		float CameraFocusPoint[3] = RT_CAMERA_FOCUS_POINT;
+		float CameraUpDirection[3] = RT_CAMERA_UP_DIRECTION;
 
 		//additions of the headless build
 		bool RebuildBVHEveryCycle = false;  //the reference builds once; true = per-frame rebuild

@@ -49,7 +49,12 @@ namespace RT::GraphicsAPI
 	{
 		if (iTextureID) *iTextureID = 0;
 		if (m_iBufferSize == 0) AddDefaultTexture();
-		if ((rtProperties.ChannelCount != 4) || (rtProperties.BytesPerChannel != 2) || !rtProperties.Data) return false;
+		if ((rtProperties.ChannelCount != 4) || (rtProperties.BytesPerChannel != 2) || !rtProperties.Data)
+		{
+			//the atlas owns the pixel data from the call on: a rejected texture's decoded pixels are released here
+			delete[] (uint8_t*)rtProperties.Data;
+			return false;
+		}
 
 		TextureID rtTextureID{};
 		rtTextureID.Offset = m_iBufferSize;
@@ -64,6 +69,14 @@ namespace RT::GraphicsAPI
 
 	void TextureAtlas::BuildHostImage(std::vector<uint8_t>& stdAtlasBytes, std::vector<TextureID>& stdIDs) const
 	{
+		if (m_iBufferSize == 0)
+		{
+			//nothing added yet: the image Initialize() would upload, i.e. the default slot alone
+			stdAtlasBytes.assign(16, 0);
+			std::memset(stdAtlasBytes.data(), 0xff, 8);
+			stdIDs.assign(1, TextureID{ 0, 1, 1, 1 });
+			return;
+		}
 		stdAtlasBytes.assign(m_iBufferSize, 0);
 		size_t iOffset = 0;
 		for (const TextureInfo& rtData : m_stdTextureData)

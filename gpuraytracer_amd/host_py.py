@@ -55,6 +55,8 @@ def load():
         "rth_pipeline_destroy": (None, [_P]),
         "rth_write_ppm": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
         "rth_write_pfm": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
+        "rth_write_png": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
+        "rth_encode_srgb8": (C.c_uint32, [C.c_float]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -132,6 +134,17 @@ def load_texture(path):
     out = np.frombuffer((C.c_uint16 * n).from_address(p), dtype=np.uint16).copy().reshape(h.value, w.value, 4)
     lib.rth_free(p)
     return out
+
+
+def write_image(path, pixels, kind=None):
+    """WriteImagePPM / WriteImagePNG / WriteImagePFM of the C++ host: pixels is a (height, width, 4) float32 image."""
+    lib = load()
+    px = np.ascontiguousarray(pixels, dtype=np.float32)
+    h, w = px.shape[:2]
+    kind = kind or str(path).rsplit(".", 1)[-1].lower()
+    fn = {"ppm": lib.rth_write_ppm, "png": lib.rth_write_png, "pfm": lib.rth_write_pfm}[kind]
+    if not fn(str(path).encode(), px.ctypes.data_as(_P), w, h):
+        raise RuntimeError("writing %s failed" % path)
 
 
 class HostPipeline:

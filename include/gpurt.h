@@ -94,15 +94,37 @@ int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats);
  * the reference's order could decide are walked again by QUAD. It can differ from the reference only in hits that are
  * numerically false: a near-degenerate triangle whose hit test accepts a ray that passes beside the triangle's own
  * (slightly widened) box, or far enough in front of it - see the kernel's description; comparisons of the two walks
- * over random scenes put that below one ray in 10^9. rt_accel_build makes the second hierarchy only while the
- * device is set to SPATIAL; an accel built under another setting is traced by QUAD until it is built again. The
- * environment variable
- * GPURT_TRACE_KERNEL = spatial | quad | wave | simple sets the initial choice of a new device. */
+ * over random scenes put that below one ray in 10^9. Whether rt_accel_build makes the second hierarchy is a property of
+ * the accel (rt_accel_set_second_hierarchy, on by default); an accel built without it is traced by QUAD. The
+ * environment variable GPURT_TRACE_KERNEL = spatial | quad | wave | simple sets the initial choice of a new device. */
 #define RT_TRACE_KERNEL_QUAD 0
 #define RT_TRACE_KERNEL_WAVE 1
 #define RT_TRACE_KERNEL_SIMPLE 2
 #define RT_TRACE_KERNEL_SPATIAL 3
 int rt_device_set_trace_kernel(rt_device* dev, int kernel);
+/* The slab test as the reference writes it (no counterpart call in the reference; it selects the reference's own
+ * arithmetic): shader/CS_TraceRays.hlsl:83-84 divides by the ray direction for every box, the kernels above multiply by
+ * one reciprocal per ray and axis, which rounds differently in the last place and lets a few rays per million enter or
+ * miss a box the other form does not. While enabled, trace calls with a hierarchy run the one-level walk (WAVE, or
+ * SIMPLE if that is selected) with the division: the reference's result as written, at a fraction of the speed. */
+int rt_device_set_slab_division(rt_device* dev, int enable);
+/* Tuning of the persistent traversal kernels (no counterpart in the reference; no setting changes a result). A new
+ * device starts from the defaults, or from the environment variables named beside the fields, read once by
+ * rt_device_create. 0 = the library's default where stated. */
+typedef struct {
+    uint32_t leaf_threshold;    /* GPURT_LEAF_THRESHOLD: lanes with a leaf waiting that start a triangle round; 0 = 32 (SPATIAL) / 16 */
+    uint32_t refill_threshold;  /* GPURT_REFILL_THRESHOLD: free lanes that start a refill; 0 = 8 (SPATIAL) / 16 */
+    uint32_t blocks_per_cu;     /* GPURT_BLOCKS_PER_CU: persistent workgroups per compute unit; default 4 */
+    uint32_t sort_rays;         /* GPURT_SORT_RAYS: 1 = order the rays of a launch by estimated walk length, 0 = as they come */
+    uint32_t deal_shift;        /* GPURT_DEAL_SHIFT: log2 of the block of ray-order positions dealt to one queue; 6 .. 20, default 6 */
+    uint32_t cost_bits;         /* GPURT_COST_BITS: bits of the walk-length class in the ray key; 6 .. 12, default 6 */
+    uint32_t cost_depth;        /* GPURT_COST_DEPTH: tree depth probed for the walk-length estimate; 0 = default (no probe on SPATIAL) */
+    uint32_t cost_stride;       /* GPURT_COST_STRIDE: every n-th node pair of that depth is probed; 0 = default */
+    uint32_t cost_chord;        /* GPURT_COST_CHORD: 1 = estimate from the ray's way through the trunk's box, 0 = probe, 2 = default */
+    uint32_t key_passes;        /* GPURT_KEY_PASSES: 8-bit sorting passes over the ray keys, 1 .. 3; 0 = default */
+} rt_trace_tuning;
+int rt_device_get_trace_tuning(rt_device* dev, rt_trace_tuning* out);
+int rt_device_set_trace_tuning(rt_device* dev, const rt_trace_tuning* tuning);   /* out-of-range values are clamped */
 /* Instrumentation (no counterpart in the reference): how many rays of the device's last trace call the SPATIAL
  * kernel handed to the walk in the reference's order (0 after a call with another kernel). Waits for the stream. */
 int rt_device_listed_rays(rt_device* dev, uint32_t* count);
@@ -194,6 +216,11 @@ uint32_t rt_bvh_node_count(uint32_t num_primitives);     /* nodes the hierarchy 
  * 1 KB per triangle in all. */
 int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out);
 int rt_accel_destroy(rt_accel* accel);
+/* Whether builds of this accel also make the library's own hierarchy (what RT_TRACE_KERNEL_SPATIAL walks; on by
+ * default where it fits), and the finest Morton cells its leaf slots may be aligned to: cell_bits in 0, 3, 6, .. 21
+ * (0 = leaves by rank only; anything above 21 means 21, the default). Takes effect at the next build; an accel whose last build did not make it is traced by
+ * RT_TRACE_KERNEL_QUAD. */
+int rt_accel_set_second_hierarchy(rt_accel* accel, int enable, uint32_t cell_bits);
 /* Gathers Indices -> Vertices -> positions into the accel's packed triangle array
  * (3 x float4 per triangle, original order). Call after the mesh changes. */
 int rt_accel_pack(rt_accel* accel, uint32_t num_primitives, const rt_buffer* indices, const rt_buffer* vertices);
