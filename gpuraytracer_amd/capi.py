@@ -130,6 +130,7 @@ SIGNATURES = {
     "rt_device_set_trace_kernel": (C.c_int, [_P, C.c_int]),
     "rt_device_listed_rays": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "rt_device_set_slab_division": (C.c_int, [_P, C.c_int]),
+    "rt_device_set_walk_margins": (C.c_int, [_P, C.c_float, C.c_float]),
     "rt_device_get_trace_tuning": (C.c_int, [_P, C.POINTER(TraceTuning)]),
     "rt_device_set_trace_tuning": (C.c_int, [_P, C.POINTER(TraceTuning)]),
     "rt_accel_set_second_hierarchy": (C.c_int, [_P, C.c_int, _U32]),

@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
                                                 const float4* __restrict__ tris, float4* __restrict__ sorted_tris,
                                                 rt_aabb* __restrict__ nodes, rt_aabb* __restrict__ pairs, float4* __restrict__ quads,
                                                 const uint32_t* __restrict__ cells, uint32_t slots_log2,
-                                                const uint32_t* __restrict__ ranks) {
+                                                const uint32_t* __restrict__ ranks, float sliver_pad) {
     __shared__ float s_box[256][6];
     // with ranks: the sixth 16 bytes of a leaf record hold the places of its two triangles in the reference's order
     __shared__ uint2 s_rank[PACKED ? 256 : 1];
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
             // tiny part of its longest edge is dominated by rounding near its long edges (its determinant is just
             // above the reference's cut-off there), and accepts rays that pass beside the triangle's box; the
             // reference finds such hits, because its leaf boxes hold an unrelated second triangle and are large. A box
-            // that is 1/32 of the longest edge wider on every side lets those rays test the triangle here too.
+            // that is sliver_pad (1/32) of the longest edge wider on every side lets those rays test the triangle here too.
             float pad = 0.0f;
 #pragma unroll
             for (int t = 0; t < 2; t++) {
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
                 const float longest = fmaxf(fmaxf(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2], e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]),
                                             e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]);
                 const float twice_area2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
-                if (twice_area2 < longest * longest * (1.0f / 4096.0f)) pad = fmaxf(pad, sqrtf(longest) * (1.0f / 32.0f));      // altitude < longest / 64
+                if (twice_area2 < longest * longest * (1.0f / 4096.0f)) pad = fmaxf(pad, sqrtf(longest) * sliver_pad);      // altitude < longest / 64
             }
 #pragma unroll
             for (int a = 0; a < 3; a++) { b.mn[a] -= pad; b.mx[a] += pad; }
@@ -1143,7 +1143,7 @@ int rt_bvh_build_leaves(rt_device* dev, const rt_bvh_info* info, const rt_buffer
     hipLaunchKernelGGL((k_leaves<false, false>), dim3(div_up(leaves, 256u)), dim3(256), 0, dev->stream, n, lv,
                        (const uint32_t*)morton_codes->ptr, (const uint32_t*)indices->ptr, (const rt_vertex*)vertices->ptr,
                        (const float4*)nullptr, (float4*)nullptr, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, (float4*)nullptr,
-                       (const uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
+                       (const uint32_t*)nullptr, 0u, (const uint32_t*)nullptr, 0.0f);
     return rt_launch_status();
 }
 
@@ -1370,7 +1370,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     const uint32_t leaves = lv.n[0];
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)src,
                        (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, a->pairs,
-                       a->quads, (const uint32_t*)nullptr, 0u, (const uint32_t*)nullptr);
+                       a->quads, (const uint32_t*)nullptr, 0u, (const uint32_t*)nullptr, 0.0f);
     for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
         hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, a->pairs, a->quads);
     if (morton_codes)
@@ -1403,7 +1403,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     hipLaunchKernelGGL(k_cell_starts, dim3(div_up(n, 256u)), dim3(256), 0, s, n, (const uint2*)sp_src, a->cells);
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(slots, 256u)), dim3(256), 0, s, 2u * slots, sl, (const uint32_t*)sp_src,
                        (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, a->sp_pairs, a->sp_quads,
-                       (const uint32_t*)a->cells, slots_log2, (const uint32_t*)a->ranks);
+                       (const uint32_t*)a->cells, slots_log2, (const uint32_t*)a->ranks, dev->walk_sliver_pad);
     for (uint32_t k0 = 8u; k0 + 1u < sl.count; k0 += 8u)
         hipLaunchKernelGGL(k_upsweep, dim3(div_up(sl.n[k0], 256u)), dim3(256), 0, s, k0, sl, a->sp_nodes, a->sp_pairs, a->sp_quads);
     return rt_launch_status();

@@ -48,6 +48,8 @@ int rt_device_create(int gpu_index, rt_device** out) {
     }
     d->slab_division = false;
     d->listed_valid = false;
+    d->walk_entry_margin = 1.00390625f;      // 1 + 2^-8
+    d->walk_sliver_pad = 1.0f / 32.0f;
     {   // tuning of the traversal kernels: defaults, or the environment's values (read here, once per device)
         auto env = [](const char* name, uint32_t fallback) -> uint32_t {
             const char* v = std::getenv(name);

@@ -34,6 +34,8 @@ struct rt_device {
     // optional event pairs around the traversal kernel (rt_device_set_traverse_timing)
     int trace_kernel;          // RT_TRACE_KERNEL_*: which traversal kernel rt_trace_rays launches
     bool slab_division;        // rt_device_set_slab_division: the box test divides by the direction, as the reference writes it
+    float walk_entry_margin;   // rt_device_set_walk_margins: SPATIAL kernel enters boxes up to reach * this
+    float walk_sliver_pad;     // ... and the builds widen own leaf boxes of slivers by this part of the longest edge
     rt_trace_tuning tuning;    // rt_device_set_trace_tuning (initial values: defaults or GPURT_* environment variables)
     int compute_units;         // of this GPU: the persistent kernels launch a multiple of it
     bool listed_valid;         // the last trace call ran the SPATIAL kernel, so queue_counter[128] is its list length

@@ -51,6 +51,7 @@ struct TraceParams {
     uint32_t queue_chunk;      // slots per queue of the persistent traversal kernel (a multiple of the dealt block)
     uint32_t refill_threshold; // lanes that must be free before a wave of k_traverse_quad takes new rays
     uint32_t deal_shift;       // blocks of 2^deal_shift consecutive positions of the ray order are dealt to the queues in turn
+    float beyond;              // k_traverse_spatial enters boxes up to reach * beyond
     rt_levels lv;
 };
 
@@ -972,7 +973,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
     // it are two roundings of (nearly) the same number - the same one for a triangle in the face of a flat box - and
     // a hit that is closer than the closest one by a rounding must not be lost behind a box that is farther by one.
     float reach_in = 0.0f;
-    constexpr float kBeyond = 1.00390625f;      // 1 + 2^-8
+    const float kBeyond = p.beyond;             // 1 + 2^-8 unless a test has asked for less (rt_device_set_walk_margins)
     bool have_hit = false, again = false;
     uint32_t h = 1u;                  // slot of the entered node
     unsigned long long trail = 0ull;
@@ -1387,6 +1388,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     // (free lanes that start a refill: taking rays from the spatial kernel's stock is cheap, a refill of the others is not)
     p.refill_threshold = tune.refill_threshold ? tune.refill_threshold : (spatial_kernel ? 8u : 16u);
     p.deal_shift = tune.deal_shift;
+    p.beyond = dev->walk_entry_margin;
     const uint32_t deal_block = 1u << p.deal_shift;
     p.queue_chunk = ((((nr + deal_block - 1u) / deal_block) + 7u) / 8u) * deal_block;      // whole blocks, dealt to the eight queues in turn
     p.lv.count = 0;
@@ -1562,6 +1564,13 @@ int rt_device_set_trace_kernel(rt_device* dev, int kernel) {
 int rt_device_set_slab_division(rt_device* dev, int enable) {
     if (!dev) return RT_ERR_INVALID_ARGUMENT;
     dev->slab_division = enable != 0;
+    return RT_OK;
+}
+
+int rt_device_set_walk_margins(rt_device* dev, float entry_margin, float sliver_pad) {
+    if (!dev || !(entry_margin >= 1.0f && entry_margin <= 2.0f) || !(sliver_pad >= 0.0f && sliver_pad <= 1.0f)) return RT_ERR_INVALID_ARGUMENT;
+    dev->walk_entry_margin = entry_margin;
+    dev->walk_sliver_pad = sliver_pad;
     return RT_OK;
 }
 

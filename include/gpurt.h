@@ -123,6 +123,12 @@ typedef struct {
     uint32_t cost_chord;        /* GPURT_COST_CHORD: 1 = estimate from the ray's way through the trunk's box, 0 = probe, 2 = default */
     uint32_t key_passes;        /* GPURT_KEY_PASSES: 8-bit sorting passes over the ray keys, 1 .. 3; 0 = default */
 } rt_trace_tuning;
+/* Diagnostics (no counterpart in the reference): the two safety margins of the SPATIAL kernel. entry_margin: boxes are
+ * entered up to reach * entry_margin (default 1 + 2^-8; 1 = no margin); sliver_pad: own leaf boxes of triangles whose
+ * altitude is below 1/64 of their longest edge are widened by sliver_pad * that edge on every side at the next build
+ * (default 1/32; 0 = no room). Smaller values make the kernel miss hits the reference finds - they exist so that tests
+ * can show what the margins are for. Values outside [1, 2] and [0, 1] are refused. */
+int rt_device_set_walk_margins(rt_device* dev, float entry_margin, float sliver_pad);
 int rt_device_get_trace_tuning(rt_device* dev, rt_trace_tuning* out);
 int rt_device_set_trace_tuning(rt_device* dev, const rt_trace_tuning* tuning);   /* out-of-range values are clamped */
 /* Instrumentation (no counterpart in the reference): how many rays of the device's last trace call the SPATIAL

@@ -402,11 +402,9 @@ def test_random_scenes_agree_between_the_two_walks(device):
     assert bad == 0
 
 
-def test_false_hit_beside_a_sliver_is_found_by_both_walks(device):
-    """The ray and the 1300:1 sliver of the one fuzzed case in which the two walks differed: Moeller-Trumbore accepts
-    the ray (determinant 2e-5) although it passes 1 % of the box size beside the triangle's bounding box. The walk in
-    the reference's order tests the triangle whenever the box of its leaf - the sliver and whatever triangle is next
-    to it in the reference's order - lets the ray in; the default kernel must then find the same hit."""
+def _sliver_scenes(device, seeds=range(12)):
+    """The ray and the 1300:1 sliver of the one fuzzed case in which the two walks differed, placed in random soups that
+    keep clear of the ray; returns per scene the ray buffers after one trace call by (SPATIAL, QUAD) and the ray."""
     from gpuraytracer_amd import capi, scenes
     from gpuraytracer_amd.capi import vertex_dtype
     from gpuraytracer_amd.pipeline import Pipeline
@@ -414,8 +412,8 @@ def test_false_hit_beside_a_sliver_is_found_by_both_walks(device):
                        [1.6871155500411987, -0.3055894076824188, -2.033355474472046],
                        [1.687436819076538, -0.30577898025512695, -2.033759355545044]], dtype=np.float32)
     ray = np.array([-11.012279, 4.101115, -6.340874, 0.8997188, -0.31224802, 0.30497092, 0.0, 11814.092], dtype=np.float32)
-    found = 0
-    for seed in range(12):
+    outs = []
+    for seed in seeds:
         rng = np.random.RandomState(seed)
         n = 3000
         pos = (rng.uniform(-10, 10, (n, 1, 3)) + rng.uniform(-0.2, 0.2, (n, 3, 3))).astype(np.float32)
@@ -451,8 +449,20 @@ def test_false_hit_beside_a_sliver_is_found_by_both_walks(device):
             finally:
                 device.lib.rt_device_set_trace_kernel(device.handle, KERNEL_SPATIAL)
                 p.close()
-        assert out[0].view(np.uint32).tobytes() == out[1].view(np.uint32).tobytes(), "the walks differ (scene seed %d)" % seed
-        found += int(not np.array_equal(out[1][0], ray))
+        outs.append((out[0], out[1]))
+    return outs, ray
+
+
+def test_false_hit_beside_a_sliver_is_found_by_both_walks(device):
+    """The ray and the 1300:1 sliver of the one fuzzed case in which the two walks differed: Moeller-Trumbore accepts
+    the ray (determinant 2e-5) although it passes 1 % of the box size beside the triangle's bounding box. The walk in
+    the reference's order tests the triangle whenever the box of its leaf - the sliver and whatever triangle is next
+    to it in the reference's order - lets the ray in; the default kernel must then find the same hit."""
+    outs, ray = _sliver_scenes(device)
+    found = 0
+    for seed, (spatial, quad) in enumerate(outs):
+        assert spatial.view(np.uint32).tobytes() == quad.view(np.uint32).tobytes(), "the walks differ (scene seed %d)" % seed
+        found += int(not np.array_equal(quad[0], ray))
     print("scenes in which the reference's walk takes the false hit:", found, "of 12")
     assert found > 0, "no scene in which the reference's order lets the ray into the sliver's leaf: the test is empty"
 

@@ -145,6 +145,27 @@ def test_c2_full_size_kernels_agree_and_tolerance_holds(device, oracle, name):
     assert a["output"][..., :3].max() > 0.0
 
 
+def test_testscene2_has_the_structure_of_the_reference_screenshot(device):
+    """The only output the reference holds, results/NoBVH.png (testscene2 without a hierarchy, 1080p, camera of
+    src/Settings.h:22-25), as 16 x 16 block means of linear RGB (tests/golden/ref_nobvh_lowfreq.npz, made by
+    scripts/make_nobvh_fixture.py). Seeds and sample count of the screenshot are unknown, so this is qualitative: the
+    luminance of our render, encoded to 8-bit sRGB as the reference presents it, correlates with the screenshot's block
+    by block, and the channel means agree once the running mean's k / (k + 1) factor is taken out (the screenshot's
+    noise level and brightness fit k = 3 accumulated samples). First check that does not come from reading the HLSL."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("compare_nobvh_png", os.path.join(ROOT, "scripts", "compare_nobvh_png.py"))
+    cmp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cmp)
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "ref_nobvh_lowfreq.npz"))["rgb"]
+    for use_bvh, cycles in ((False, 3), (True, 3), (True, 12)):
+        corr, log_corr, ratio = cmp.compare(cmp.low_frequency(cmp.render(device, cycles, use_bvh)), ref)
+        unscaled = ratio / ((cycles / (cycles + 1.0)) / 0.75)
+        print("testscene2 %s, %d cycles vs results/NoBVH.png: luminance correlation %.4f (log %.4f), channel mean ratios %s, "
+              "without the k/(k+1) factors %s" % ("BVH" if use_bvh else "NoBVH", cycles, corr, log_corr, np.round(ratio, 3), np.round(unscaled, 3)))
+        assert corr >= 0.97 and log_corr >= 0.95
+        assert np.all(np.abs(unscaled - 1.0) <= 0.1)
+
+
 # ------------------------------------------------------------------ C4: rows dealt to 8 pseudo-ranks ----
 
 def test_c4_rows_dealt_to_eight_ranks_assemble_to_the_unsharded_image(device, oracle):
@@ -260,6 +281,54 @@ def test_c5_fifty_million_moving_triangles(device, oracle):
     q = _gpu_render(device, oracle, sc, w, h, 2, depth, kernel=KERNEL_QUAD, keep=ALL, dynamic=True)
     _same(a, q, "C5 480x270: SPATIAL vs QUAD")
     assert a["output"][..., :3].max() > 0.0
+
+
+# ------------------------------------------------------------------ what the default kernel's two margins are for ----
+
+def test_sliver_room_decides_the_false_hit(device):
+    """The room around slivers in the library's own leaf boxes (default: 1/32 of the longest edge): with it every scene
+    of the sliver case agrees with the walk in the reference's order; without it (pad 0) or with too little (1/1024)
+    the default kernel loses the hit the reference finds in at least one scene."""
+    from gpuraytracer_amd import capi
+    from tests.test_gpu_parity import _sliver_scenes
+    lib = device.lib
+    differing = {}
+    try:
+        for pad in (0.0, 1.0 / 1024.0, 1.0 / 32.0, 1.0 / 8.0):
+            capi.check(lib.rt_device_set_walk_margins(device.handle, 1.00390625, pad), "rt_device_set_walk_margins")
+            outs, _ = _sliver_scenes(device)
+            differing[pad] = sum(int(a.view(np.uint32).tobytes() != b.view(np.uint32).tobytes()) for a, b in outs)
+    finally:
+        lib.rt_device_set_walk_margins(device.handle, 1.00390625, 1.0 / 32.0)
+    print("scenes (of 12) in which the two walks differ, by sliver pad:", differing)
+    assert differing[1.0 / 32.0] == 0 and differing[1.0 / 8.0] == 0
+    assert differing[0.0] > 0, "without the room the false hit beside the sliver must be lost"
+    assert lib.rt_device_set_walk_margins(device.handle, 0.5, 0.1) == capi.RT_ERR_INVALID_ARGUMENT
+    assert lib.rt_device_set_walk_margins(device.handle, 1.0, 2.0) == capi.RT_ERR_INVALID_ARGUMENT
+
+
+def test_entry_margin_decides_hits_behind_rounded_boxes(device):
+    """Boxes are entered up to reach * (1 + 2^-8): a hit distance and the entry distance of a flat box around the
+    triangle are two roundings of the same number. On axis-aligned quads of a grid (overlapping coplanar triangles, flat
+    boxes) a margin of 1 loses hits the reference finds; the default margin loses none."""
+    import importlib.util
+    from gpuraytracer_amd import capi
+    spec = importlib.util.spec_from_file_location("fuzz_walks", os.path.join(ROOT, "scripts", "fuzz_walks.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    lib = device.lib
+    os.environ["FUZZ_KINDS"], os.environ["FUZZ_MAX_EXP"] = "quads,inplane", "4.3"
+    bad = {}
+    try:
+        for margin in (1.0, 1.00390625):
+            capi.check(lib.rt_device_set_walk_margins(device.handle, margin, 1.0 / 32.0), "rt_device_set_walk_margins")
+            bad[margin], _ = fuzz.run(device, 24, 1, verbose=False)
+    finally:
+        os.environ.pop("FUZZ_KINDS"), os.environ.pop("FUZZ_MAX_EXP")
+        lib.rt_device_set_walk_margins(device.handle, 1.00390625, 1.0 / 32.0)
+    print("grid-quad scenes (of 24) in which the two walks differ, by entry margin:", bad)
+    assert bad[1.00390625] == 0
+    assert bad[1.0] > 0, "without the margin hits behind boxes that are farther by a rounding must be lost"
 
 
 # ------------------------------------------------------------------ settings of the boundary ----
