@@ -15,7 +15,8 @@ does; --scaling strong keeps 1 ray per pixel instead).
 
 Rank 0 prints ONE JSON line: Mrays/s over the whole job (a ray = one ray segment handled by one trace
 thread in one trace launch), the LBVH build time, a roofline object for the dominant kernel (the
-trace kernel; algorithmic bytes from exact traversal counters) and the CPU baseline (the scalar
+traversal launch: bytes across the memory side from the committed hardware-counter passes over the launch duration
+measured live, the vector units' utilisation from the same passes) and the CPU baseline (the scalar
 OpenMP oracle timed on a bounded sample of the same workload on this host).
 """
 import argparse
@@ -31,18 +32,53 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak
-# Morton 56 + sort 80 + leaves 68 + upper levels 48 (reference data layout) for the reference's hierarchy, and the same
-# again for the library's own hierarchy (its keys are made from the sorted pairs and the packed triangles: 56 as well)
-BUILD_BYTES_PER_TRIANGLE = 2 * 252
+# Algorithmic bytes of one LBVH build per triangle in the reference's data layout: Morton codes 56 (12 B of indices,
+# 36 B of positions, 8 B key + value out), radix sort 80 (4 passes x (4 B key read for the count + 8 B read + 8 B
+# written)), leaves 68, upper levels 48.
+BUILD_BYTES_PER_TRIANGLE = 252
+ROUND = "r2"
+NUM_SIMDS = 1024                # 256 compute units x 4
+NUM_XCDS = 8
 
-# HBM-side bytes of ONE k_traverse_quad launch of the default workload on one GPU, from the hardware-counter passes
-# committed as profiles/r1_c3_final_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in runs of their
-# own, kilobytes -> bytes): the kernel's reads past L2 are gathers of 64-byte requests, for which FETCH_SIZE counts
-# the bytes exactly (scripts/calib_fetch.hip; the doubling the microarchitecture guide prescribes applies to wide
-# streaming reads, which this kernel does not issue). Counters cannot be read inside a timed run, so the figure is
-# carried here and reported only for the configuration it was measured on.
-MEASURED_TRAFFIC = {("c3", 1, "spatial"): {"fetch": 7374910.8e3, "write": 463644.2e3, "source": "profiles/r1_c3_spatial_pmc_summary.txt"},
-                    ("c3", 1, "quad"): {"fetch": 147772356.0e3, "write": 489338.2e3, "source": "profiles/r1_c3_final_pmc_summary.txt"}}
+
+def load_pmc(workload, kernel):
+    """Per-dispatch hardware counters of `kernel` from the committed counter passes of this workload
+    (profiles/<round>_<workload>_pmc.json, written by scripts/pmc_summary.py --json from scripts/pmc_passes.sh runs:
+    one rocprofv3 --pmc run per counter group). None when there is no such file or kernel."""
+    path = os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (ROUND, workload))
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        table = json.load(f)
+    for name in (kernel + "<false>", kernel):
+        if name in table["kernels"]:
+            return table["kernels"][name], os.path.relpath(path, ROOT)
+    return None, None
+
+
+def counter_fractions(c, avg_launch_s):
+    """The two roofline fractions of a traversal launch from its counters:
+    memory side = bytes that crossed the L2's memory side (FETCH_SIZE + WRITE_SIZE, KiB; 64-byte gathers, for which
+    FETCH_SIZE counts exactly) / launch duration / HBM peak;
+    vector side = share of cycles the SIMDs' vector units were issuing (SQ_ACTIVE_INST_VALU, quad-cycles summed over
+    the 1024 SIMDs, against GRBM_GUI_ACTIVE summed over the 8 XCDs) x share of the 64 lanes active in those
+    instructions (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU))."""
+    out = {}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        traffic = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        out["traffic"] = int(traffic)
+        out["memory"] = {"fetch_bytes": int(c["FETCH_SIZE"] * 1024), "write_bytes": int(c["WRITE_SIZE"] * 1024),
+                         "achieved": round(traffic / avg_launch_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBPS, 4)}
+        if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+            out["memory"]["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0), 4)
+    if all(k in c for k in ("SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE")):
+        busy = (c["SQ_ACTIVE_INST_VALU"] * 4.0 / NUM_SIMDS) / (c["GRBM_GUI_ACTIVE"] / NUM_XCDS)
+        lanes = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+        out["vector"] = {"valu_busy": round(busy, 4), "active_lane_fraction": round(lanes, 4), "frac": round(busy * lanes, 4),
+                         "unit": "share of the vector units' lane slots doing work", "valu_instructions": int(c.get("SQ_INSTS_VALU", 0))}
+    return out
+
 
 WORKLOADS = {
     # name: (triangles, width, height, rays/pixel, bounces, description)
@@ -263,10 +299,35 @@ def main():
     achieved = bytes_per_launch / avg_trace_s / 1e9
     avg_build_ms = float(np.mean(build_ms))
 
-    tkey = (args.workload, world)
-    plain = not (args.triangles or args.width or args.height or args.band or args.dynamic) and args.scaling == "weak"
-    traffic = MEASURED_TRAFFIC.get(tkey + (kernel_name,)) if plain else None
+    plain = not (args.triangles or args.width or args.height or args.band or args.dynamic) and args.scaling == "weak" and world == 1
     kernel_symbol = {"spatial": "k_traverse_spatial", "quad": "k_traverse_quad", "wave": "k_traverse", "simple": "k_trace"}.get(kernel_name, kernel_name)
+    counters, counter_file = load_pmc(args.workload, kernel_symbol) if plain else (None, None)
+    fr = counter_fractions(counters, avg_trace_s) if counters else {}
+    mem, vec = fr.get("memory"), fr.get("vector")
+    # the roofline of the dominant kernel, the traversal launch: HBM is the contract's bound for this path (no dense
+    # contraction anywhere); frac is what crossed the memory side over the launch's duration, against the HBM peak.
+    # The unit that binds the kernel today is named in `binding`.
+    roofline = {"kernel": kernel_symbol, "bound": "hbm",
+                "achieved": mem["achieved"] if mem else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": mem["frac"] if mem else None,
+                "traffic": fr.get("traffic"),
+                "traffic_source": (counter_file + ": FETCH_SIZE + WRITE_SIZE per launch x 1024 (separate --pmc passes)") if mem else None,
+                "memory": mem, "vector": vec,
+                "binding": (("vector units (vector.frac %.2f against memory.frac %.2f)" % (vec["frac"], mem["frac"]))
+                            if vec["frac"] >= mem["frac"] else ("memory side (memory.frac %.2f against vector.frac %.2f)" % (mem["frac"], vec["frac"])))
+                if mem and vec else None,
+                "avg_launch_ms": round(avg_trace_s * 1e3, 4), "launches_timed": int(kernel_launches.value),
+                "avg_trace_call_ms": round(avg_trace_call_ms, 4), "rays_per_launch": local_rays,
+                "note": "achieved = bytes across the L2's memory side per launch (hardware counters of the committed passes of this "
+                        "workload) / the launch duration measured live in this run (HIP events on the library's stream around the "
+                        "traversal kernel). algorithmic_* are the reference walk's own counts in the reference's data layout "
+                        "(100 B per ray + 32 B per box test + 48 B per triangle test + hit traffic), kept for "
+                        "reference; the default kernel finds the same closest hits with far fewer tests, so they are not a fraction "
+                        "of anything it does"}
+    if counted:
+        roofline.update({"algorithmic_bytes_per_launch": int(bytes_per_launch), "algorithmic_gbps_if_performed": round(achieved, 1),
+                         "algorithmic_box_tests_per_ray": round(nodes / max(counted, 1), 2),
+                         "algorithmic_triangle_tests_per_ray": round(tris / max(counted, 1), 3), "hit_fraction": round(hits / max(counted, 1), 4)})
+    build_bytes = BUILD_BYTES_PER_TRIANGLE * ntri
     out = {
         "metric": "Mrays/sec", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
@@ -278,23 +339,15 @@ def main():
                    "triangles": ntri, "width": width, "height": height, "rays_per_pixel": rpp, "bounces": depth,
                    "parallelism": "image rows dealt to %d GPU(s) in turn, replicated scene + per-GPU rebuild, gather to rank 0" % world},
         "lbvh_build_ms": round(avg_build_ms, 4),
-        "roofline": {"kernel": kernel_symbol, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                     "traffic": int(traffic["fetch"] + traffic["write"]) if traffic else None,
-                     "traffic_source": traffic["source"] + " (FETCH_SIZE + WRITE_SIZE per launch)" if traffic else None,
-                     "note": "algorithmic bytes are those of the reference's walk in the reference's data layout (its box and "
-                             "triangle tests per ray, counted exactly, x 32 B and 48 B). k_traverse_quad performs those tests, "
-                             "mostly from L1/L2; k_traverse_spatial returns the same closest hits from a hierarchy of its own "
-                             "with far fewer tests, so achieved exceeds the HBM peak - traffic is what crossed the memory side",
-                     "avg_launch_ms": round(avg_trace_s * 1e3, 4), "launches_timed": int(kernel_launches.value),
-                     "avg_trace_call_ms": round(avg_trace_call_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                     "rays_per_launch": local_rays, "box_tests_per_ray": round(nodes / max(counted, 1), 2),
-                     "triangle_tests_per_ray": round(tris / max(counted, 1), 3), "hit_fraction": round(hits / max(counted, 1), 4)},
-        "build_roofline": {"kernels": "both hierarchies: (k_morton_packed | k_spatial_keys) + 4 x (k_sort_hist, k_sort_scan, k_sort_scatter) + k_leaves + k_upsweep, each",
-                           "bound": "hbm", "achieved": round(BUILD_BYTES_PER_TRIANGLE * ntri / (avg_build_ms * 1e-3) / 1e9, 2),
+        "roofline": roofline,
+        # 252 B per triangle (reference layout) over the time a frame pays for its build - both hierarchies, and for a
+        # moving scene also the animation and the bounds - and, below, over the reference's hierarchy alone
+        "build_roofline": {"kernels": "per frame: k_morton_packed, radix passes, k_leaves, k_upsweep for the reference's hierarchy; "
+                                      "keys, radix passes, cell layout, k_leaves, k_upsweep for the library's own",
+                           "bound": "hbm", "achieved": round(build_bytes / (avg_build_ms * 1e-3) / 1e9, 1),
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": round(BUILD_BYTES_PER_TRIANGLE * ntri / (avg_build_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                           "algorithmic_bytes_per_triangle": BUILD_BYTES_PER_TRIANGLE},
+                           "frac": round(build_bytes / (avg_build_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                           "algorithmic_bytes_per_triangle": BUILD_BYTES_PER_TRIANGLE, "build_ms_per_frame": round(avg_build_ms, 4)},
         "trace_ms_by_bounce": [round(float(x), 3) for x in np.asarray(trace_ms).reshape(-1, depth).mean(axis=0)],
         "image_mean": round(float(img[..., :3].mean()), 6),
     }
@@ -302,6 +355,9 @@ def main():
         out["reference_order_walk"] = ref_walk
         # lbvh_build_ms is what a frame pays: the reference's hierarchy and the library's own; this is the former alone
         out["reference_lbvh_build_ms"] = ref_walk["lbvh_build_ms"]
+        rb = ref_walk["lbvh_build_ms"] * 1e-3
+        out["build_roofline"]["reference_hierarchy_alone"] = {"build_ms": ref_walk["lbvh_build_ms"], "achieved": round(build_bytes / rb / 1e9, 1),
+                                                              "frac": round(build_bytes / rb / 1e9 / HBM_PEAK_GBPS, 4)}
     if walk:
         # what k_traverse_spatial itself reads and writes per launch in its own layout: 32 B ray + 8 B order entry in,
         # 20 B hit record out, 48 B of a 64-byte record per step, 88 B of a leaf record per leaf tested
@@ -310,9 +366,9 @@ def main():
         out["roofline"]["own_layout"] = {
             "steps_per_ray": round(walk[0] / (local_rays * launches), 2), "empty_steps_per_ray": round(walk[1] / (local_rays * launches), 2),
             "leaves_per_ray": round(walk[2] / (local_rays * launches), 2), "bytes_per_launch": int(own_bytes),
-            "achieved": round(own_bytes / avg_trace_s / 1e9, 2), "unit": "GB/s", "frac": round(own_bytes / avg_trace_s / 1e9 / HBM_PEAK_GBPS, 4),
-            "note": "bytes the kernel requests in its own data layout (mostly L1/L2 hits); the kernel is bound by vector "
-                    "instructions and divergence, see DESIGN.md section 5"}
+            "requested_gbps": round(own_bytes / avg_trace_s / 1e9, 2),
+            "note": "bytes the kernel requests in its own data layout (mostly L1/L2 hits: requested, not fetched - compare "
+                    "with `traffic`); not a roofline fraction"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (scalar OpenMP restatement of the reference shaders) on a bounded sample -
@@ -324,6 +380,17 @@ def main():
         m = oracle.sort_primitives(scene)
         oracle.build_bvh(scene, m)
         cpu_build_ms = (time.perf_counter() - tb) * 1e3
+        # the sort exactly as the shaders are written (count, 256-entry scan, and CS_SortSort's scatter in which thread d
+        # walks over all N records, shader/CS_SortSort.hlsl:18-35) on a bounded share of the triangles: O(256 N) per pass
+        n_aw = min(ntri, 200000)
+        sub = dict(scene)
+        sub["indices"] = scene["indices"][:3 * n_aw]
+        ta = time.perf_counter()
+        oracle.sort_primitives(sub, as_written=True)
+        sort_as_written_ms = (time.perf_counter() - ta) * 1e3
+        ta = time.perf_counter()
+        oracle.sort_primitives(sub)
+        sort_stable_ms = (time.perf_counter() - ta) * 1e3
         op = oracle.Pipeline(scene, cw, ch, rpp=rpp, depth=depth, seed_raygen=1, seed_trace=2)
         tt = time.perf_counter()
         op.render(depth)
@@ -335,6 +402,12 @@ def main():
                                "sample": "one frame of the same scene and camera at %dx%d (1/%d of the rays), %d bounces; "
                                          "LBVH build of the full %d triangles timed separately" % (cw, ch, div * div, depth, ntri),
                                "lbvh_build_ms": round(cpu_build_ms, 2),
+                               "lbvh_build_variant": "Morton codes + four std::stable_sort passes by digit (what the reference's sort "
+                                                     "computes) + leaves + levels, %d triangles" % ntri,
+                               "sort_as_written_ms": round(sort_as_written_ms, 2), "sort_stable_sort_ms": round(sort_stable_ms, 2),
+                               "sort_sample": "Morton codes + 4 passes on the first %d triangles: as written (CS_SortCount, "
+                                              "CS_SortPrefixSum, CS_SortSort with one thread per digit over all records) beside the "
+                                              "std::stable_sort variant" % n_aw,
                                "box_tests_per_ray": round(tot["nodes_visited"] / max(tot["rays"], 1), 2)}
 
     if rank == 0:
