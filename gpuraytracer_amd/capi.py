@@ -28,6 +28,8 @@ RT_ERR_TOO_FEW_PRIMITIVES = 2
 RT_ERR_BUFFER_TOO_SMALL = 3
 RT_ERR_OUT_OF_MEMORY = 4
 RT_ERR_LIMIT_EXCEEDED = 5
+RT_ERR_RCCL_UNAVAILABLE = 6
+RT_COMM_ID_BYTES = 128
 
 # numpy views of the element layouts (shader/Raytracer.hlsli:15-40 of the reference)
 vertex_dtype = np.dtype([("position", "<f4", 3), ("uv", "<f4", 2), ("normal", "<f4", 3), ("tangent", "<f4", 3),
@@ -130,6 +132,7 @@ SIGNATURES = {
     "rt_device_set_trace_kernel": (C.c_int, [_P, C.c_int]),
     "rt_device_listed_rays": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "rt_device_set_slab_division": (C.c_int, [_P, C.c_int]),
+    "rt_device_set_drop_missed_rays": (C.c_int, [_P, C.c_int]),
     "rt_device_set_walk_margins": (C.c_int, [_P, C.c_float, C.c_float]),
     "rt_device_get_trace_tuning": (C.c_int, [_P, C.POINTER(TraceTuning)]),
     "rt_device_set_trace_tuning": (C.c_int, [_P, C.POINTER(TraceTuning)]),
@@ -140,6 +143,14 @@ SIGNATURES = {
     "rt_accel_pack_bounds": (C.c_int, [_P, _U32, _P, _P, _P]),
     "rt_accel_build_device_bounds": (C.c_int, [_P, _P, _P, _P]),
     "rt_synthetic_animate": (C.c_int, [_P, _U32, _U32, _P, _P]),
+    "rt_rows_for_rank": (C.c_int, [_U32, _U32, _U32, C.POINTER(ImageRows)]),
+    "rt_rows_interleave": (C.c_int, [_P, _P, _U32, _U32, _U32, _P]),
+    "rt_comm_unique_id": (C.c_int, [_P]),
+    "rt_comm_init": (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    "rt_comm_destroy": (C.c_int, [_P]),
+    "rt_comm_rank": (C.c_int, [_P]),
+    "rt_comm_world": (C.c_int, [_P]),
+    "rt_gather_rows": (C.c_int, [_P, _P, _U32, _U32, C.c_int, _P]),
     "rt_trace_rays_accel": (C.c_int, [_P, C.POINTER(TraceRaysInfo), _P, _P, _P, _P, _P, _P, _U32, _P, _P, _P, _P, _P, _P, C.POINTER(ImageRows)]),
 }
 

@@ -1140,6 +1140,7 @@ int rt_bvh_build_leaves(rt_device* dev, const rt_bvh_info* info, const rt_buffer
     if (rc) return rc;
     rt_levels lv;
     lv.count = 0;
+    dev->missed_valid = false;          // a new hierarchy: rays that missed the old scene may hit this one
     hipLaunchKernelGGL((k_leaves<false, false>), dim3(div_up(leaves, 256u)), dim3(256), 0, dev->stream, n, lv,
                        (const uint32_t*)morton_codes->ptr, (const uint32_t*)indices->ptr, (const rt_vertex*)vertices->ptr,
                        (const float4*)nullptr, (float4*)nullptr, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, (float4*)nullptr,
@@ -1361,6 +1362,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     int rc = rt_set_device(dev);
     if (rc) return rc;
     hipStream_t s = dev->stream;
+    dev->missed_valid = false;          // a new hierarchy: rays that missed the old scene may hit this one
 
     hipLaunchKernelGGL(k_morton_packed, dim3(div_up(n, 256u)), dim3(256), 0, s, make_bounds(scene_min, scene_max), dbounds, n,
                        a->tris, a->keys_a);

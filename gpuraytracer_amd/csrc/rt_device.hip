@@ -47,6 +47,11 @@ int rt_device_create(int gpu_index, rt_device** out) {
                                                              : RT_TRACE_KERNEL_SPATIAL;
     }
     d->slab_division = false;
+    d->drop_missed = false;
+    d->missed = nullptr;
+    d->missed_valid = false;
+    d->missed_rays = nullptr;
+    d->missed_count = 0;
     d->listed_valid = false;
     d->walk_entry_margin = 1.00390625f;      // 1 + 2^-8
     d->walk_sliver_pad = 1.0f / 32.0f;
@@ -101,6 +106,7 @@ int rt_device_destroy(rt_device* dev) {
     if (dev->ray_keys_a) (void)hipFree(dev->ray_keys_a);
     if (dev->ray_keys_b) (void)hipFree(dev->ray_keys_b);
     if (dev->listed_rays) (void)hipFree(dev->listed_rays);
+    if (dev->missed) (void)hipFree(dev->missed);
     if (dev->conv_pairs) (void)hipFree(dev->conv_pairs);
     if (dev->conv_tris) (void)hipFree(dev->conv_tris);
     if (dev->conv_quads) (void)hipFree(dev->conv_quads);
@@ -142,6 +148,8 @@ const char* rt_error_string(int code) {
         case RT_ERR_LIMIT_EXCEEDED: return "size beyond the fixed limit of an entry point that allocates nothing";
         default: break;
     }
+    if (code == RT_ERR_RCCL_UNAVAILABLE) return "librccl.so.1 could not be loaded";
+    if (code >= RT_ERR_RCCL_BASE) return rt_comm_error_string(code);
     if (code >= RT_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(code - RT_ERR_HIP_BASE));
     return "unknown error";
 }

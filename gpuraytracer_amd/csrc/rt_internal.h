@@ -38,6 +38,11 @@ struct rt_device {
     float walk_sliver_pad;     // ... and the builds widen own leaf boxes of slivers by this part of the longest edge
     rt_trace_tuning tuning;    // rt_device_set_trace_tuning (initial values: defaults or GPURT_* environment variables)
     int compute_units;         // of this GPU: the persistent kernels launch a multiple of it
+    bool drop_missed;          // rt_device_set_drop_missed_rays
+    uint8_t* missed;           // [hit_capacity] one mark per ray: it missed in an earlier trace call of the current rays
+    bool missed_valid;         // the marks belong to the rays of the last trace call (false: cleared before the next one)
+    const void* missed_rays;   // ... whose ray buffer and ray count these were
+    uint32_t missed_count;
     bool listed_valid;         // the last trace call ran the SPATIAL kernel, so queue_counter[128] is its list length
     bool time_traverse;
     hipEvent_t* timing_events;      // [2 * timing_capacity]: start, stop, start, stop, ...
@@ -108,6 +113,8 @@ int rt_sort_workspace(rt_device* dev, uint32_t num_elements);   // grows dev->so
 // Looks up, once per GPU and with that GPU current, the device address of the static scratch array behind
 // rt_scene_bounds_static (defined beside the array in rt_build.hip); rt_device_create calls it.
 int rt_static_scratch_init(int gpu);
+// text of an RT_ERR_RCCL_BASE + ncclResult_t code (rt_comm.hip; loads RCCL if it is not loaded yet)
+const char* rt_comm_error_string(int code);
 // Stable LSD radix sort of (key, value) pairs by the low 8 * passes key bits, queued on the device's stream.
 // a and b hold n pairs each and are both overwritten; *sorted receives whichever of them holds the result.
 int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted);

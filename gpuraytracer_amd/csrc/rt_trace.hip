@@ -313,7 +313,7 @@ __device__ __forceinline__ bool pop_node(uint32_t& k, uint32_t& i, uint32_t root
 // ---- simple form: one thread per ray through traversal and shading (also the RT_USE_BVH = 0 path) ----
 template <bool USE_BVH, bool STATS, bool DIV = false>
 __global__ __launch_bounds__(256) void k_trace(TraceParams p, ShadeBuffers b, const float4* __restrict__ nodes,
-                                               unsigned long long* __restrict__ stats) {
+                                               unsigned long long* __restrict__ stats, uint8_t* __restrict__ missed) {
     __shared__ uint32_t s_off[33];
     __shared__ uint32_t s_n[33];
     if (USE_BVH) {
@@ -322,6 +322,8 @@ __global__ __launch_bounds__(256) void k_trace(TraceParams p, ShadeBuffers b, co
     }
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     if (tid >= p.num_rays) return;
+    // drop-missed-rays mode: a ray that missed stays as it is until new camera rays come, and would miss again
+    if (missed && missed[tid]) return;
 
     const float4 r0 = b.rays[2 * (size_t)tid], r1 = b.rays[2 * (size_t)tid + 1];
     const f3 org = mk(r0.x, r0.y, r0.z), dir = mk(r0.w, r1.x, r1.y);
@@ -365,6 +367,7 @@ __global__ __launch_bounds__(256) void k_trace(TraceParams p, ShadeBuffers b, co
         }
     }
     if (STATS) add_stats(stats, n_nodes, n_tris, (best.t != tmax_r) ? 1u : 0u, 1u);
+    if (missed && best.t == tmax_r) missed[tid] = 1u;
     shade_ray(p, b, tid, r0, r1, best, best_ci);
 }
 
@@ -458,9 +461,16 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
                                                   const float4* __restrict__ pairs, const float4* __restrict__ sorted_tris,
                                                   float4* __restrict__ hit_records, uint32_t* __restrict__ hit_ci,
                                                   uint32_t* __restrict__ queue, const uint2* __restrict__ order,
-                                                  unsigned long long* __restrict__ stats) {
+                                                  unsigned long long* __restrict__ stats, const uint32_t* __restrict__ live) {
     extern __shared__ uint32_t s_dyn[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (live) {
+        // drop-missed-rays mode: the rays to walk are the first *live entries of order (k_ray_keys put the others last)
+        p.num_rays = *live;
+        if (p.num_rays == 0u) return;
+        const uint32_t deal_block = 1u << p.deal_shift;
+        p.queue_chunk = ((((p.num_rays + deal_block - 1u) >> p.deal_shift) + 7u) / 8u) * deal_block;
+    }
     const uint32_t root_level = p.lv.count - 1u;
     const uint32_t first_leaf = 1u << root_level;              // slot of leaf 0
     const uint32_t first_leaf_parent = first_leaf >> 1;        // nodes from this slot on have leaves as children
@@ -940,9 +950,17 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                                                        uint32_t* __restrict__ hit_ci, uint32_t* __restrict__ queue,
                                                        const uint2* __restrict__ order, const float4* __restrict__ ref_tris,
                                                        const uint32_t* __restrict__ ranks, uint2* __restrict__ flagged,
-                                                       uint32_t* __restrict__ flag_count, unsigned long long* __restrict__ walk_stats) {
+                                                       uint32_t* __restrict__ flag_count, unsigned long long* __restrict__ walk_stats,
+                                                       const uint32_t* __restrict__ live) {
     extern __shared__ uint32_t s_dyn[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (live) {
+        // drop-missed-rays mode: the rays to walk are the first *live entries of order (k_ray_keys put the others last)
+        p.num_rays = *live;
+        if (p.num_rays == 0u) return;
+        const uint32_t deal_block = 1u << p.deal_shift;
+        p.queue_chunk = ((((p.num_rays + deal_block - 1u) >> p.deal_shift) + 7u) / 8u) * deal_block;
+    }
     const uint32_t root_level = p.lv.count - 1u;               // >= 2
     const uint32_t first_leaf = 1u << root_level;              // slot of leaf 0
     const uint32_t first_leaf_grandparent = first_leaf >> 2;   // nodes from this slot on have leaves as grandchildren
@@ -1235,8 +1253,17 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {      // abcd -> a00b00
 __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float4* __restrict__ rays,
                                                   const float4* __restrict__ nodes, const float4* __restrict__ pairs,
                                                   uint32_t first_record, uint32_t num_records, uint32_t record_stride,
-                                                  uint32_t cost_shift, uint32_t cost_bits, uint32_t key_bits, uint2* __restrict__ keys) {
+                                                  uint32_t cost_shift, uint32_t cost_bits, uint32_t key_bits, uint2* __restrict__ keys,
+                                                  const uint8_t* __restrict__ missed, uint32_t* __restrict__ live) {
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    if (missed) {
+        // drop-missed-rays mode: rays that have missed get the largest key (they sort behind every live ray, whose keys stay
+        // below it) and are not counted; the traversal walks the first *live entries of the sorted order only
+        const bool alive = tid < num_rays && !missed[tid];
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
+        if ((threadIdx.x & 63u) == 0u && m) atomicAdd(live, (uint32_t)__popcll(m));
+        if (tid < num_rays && !alive) { keys[tid] = make_uint2(0xffffffffu >> (32u - key_bits), tid); return; }
+    }
     if (tid >= num_rays) return;
     const float4 lo = nodes[0], hi = nodes[1];
     const float4 r0 = rays[2 * (size_t)tid], r1 = rays[2 * (size_t)tid + 1];
@@ -1273,15 +1300,19 @@ __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float
     const uint32_t dkey = spread3(dx) | (spread3(dy) << 1) | (spread3(dz) << 2);      // 6 bits
     // 24 bits: the (descending) cost class leads, the locality bits that still fit follow
     // (key_bits = 8: the class alone, one sorting pass - rays of a class keep the order they come in)
-    keys[tid] = make_uint2((((top_class - cost_class) << (24u - cost_bits)) | (((okey << 6) | dkey) >> (cost_bits - 6u))) >> (24u - key_bits), tid);
+    uint32_t key = (((top_class - cost_class) << (24u - cost_bits)) | (((okey << 6) | dkey) >> (cost_bits - 6u))) >> (24u - key_bits);
+    if (missed) key = min(key, (0xffffffffu >> (32u - key_bits)) - 1u);
+    keys[tid] = make_uint2(key, tid);
 }
 
 __global__ __launch_bounds__(256) void k_shade(TraceParams p, ShadeBuffers b, const float4* __restrict__ hit_records,
-                                               const uint32_t* __restrict__ hit_ci) {
+                                               const uint32_t* __restrict__ hit_ci, uint8_t* __restrict__ missed) {
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     if (tid >= p.num_rays) return;
+    if (missed && missed[tid]) return;           // not walked by this call: it would have missed again, which changes nothing
     const float4 r0 = b.rays[2 * (size_t)tid], r1 = b.rays[2 * (size_t)tid + 1];
     const float4 h = hit_records[tid];
+    if (missed && h.x == r1.w) missed[tid] = 1u;
     Hit best;
     best.t = h.x; best.u = h.y; best.v = h.z; best.w = h.w;
     shade_ray(p, b, tid, r0, r1, best, hit_ci[tid]);
@@ -1297,12 +1328,15 @@ int trace_workspace(rt_device* dev, uint32_t num_rays) {
     if (dev->ray_keys_a) { (void)hipFree(dev->ray_keys_a); dev->ray_keys_a = nullptr; }
     if (dev->ray_keys_b) { (void)hipFree(dev->ray_keys_b); dev->ray_keys_b = nullptr; }
     if (dev->listed_rays) { (void)hipFree(dev->listed_rays); dev->listed_rays = nullptr; }
+    if (dev->missed) { (void)hipFree(dev->missed); dev->missed = nullptr; }
+    dev->missed_valid = false;
     dev->hit_capacity = 0;
     hipError_t e = hipMalloc((void**)&dev->hit_records, (size_t)num_rays * 16u);
     if (e == hipSuccess) e = hipMalloc((void**)&dev->hit_ci, (size_t)num_rays * 4u);
     if (e == hipSuccess) e = hipMalloc((void**)&dev->ray_keys_a, (size_t)num_rays * 8u);
     if (e == hipSuccess) e = hipMalloc((void**)&dev->ray_keys_b, (size_t)num_rays * 8u);
     if (e == hipSuccess) e = hipMalloc((void**)&dev->listed_rays, (size_t)num_rays * 8u);
+    if (e == hipSuccess) e = hipMalloc((void**)&dev->missed, (size_t)num_rays);
     if (e != hipSuccess) return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
     dev->hit_capacity = num_rays;
     return RT_OK;
@@ -1413,25 +1447,43 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     const float4* st = accel ? (const float4*)accel->sorted_tris : nullptr;
     hipStream_t s = dev->stream;
 
+    if (dev->drop_missed || (use_bvh && !simple_kernel)) {      // (the one-thread-per-ray paths need no workspace of their own)
+        rc = trace_workspace(dev, nr);
+        if (rc) return rc;
+    }
+    // drop-missed-rays mode (rt_device_set_drop_missed_rays): one byte per ray, set by the shading step of the call in which
+    // the ray missed. The marks belong to one set of rays: they start from zero whenever the rays may be new (new camera
+    // rays, a new hierarchy, another ray buffer or count, the mode switched on).
+    uint8_t* missed = nullptr;
+    if (dev->drop_missed) {
+        if (!dev->missed_valid || dev->missed_rays != rays->ptr || dev->missed_count != nr) {
+            RT_HIP(hipMemsetAsync(dev->missed, 0, nr, s));
+            dev->missed_valid = true;
+            dev->missed_rays = rays->ptr;
+            dev->missed_count = nr;
+        }
+        missed = dev->missed;
+    }
     if (!use_bvh) {
-        if (stats) hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, s, p, b, nodes, stats);
-        else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, s, p, b, nodes, stats);
+        if (stats) hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, s, p, b, nodes, stats, missed);
+        else hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, s, p, b, nodes, stats, missed);
         return rt_launch_status();
     }
     if (simple_kernel) {
         if (divide) {
-            if (stats) hipLaunchKernelGGL((k_trace<true, true, true>), grid, block, 0, s, p, b, nodes, stats);
-            else hipLaunchKernelGGL((k_trace<true, false, true>), grid, block, 0, s, p, b, nodes, stats);
+            if (stats) hipLaunchKernelGGL((k_trace<true, true, true>), grid, block, 0, s, p, b, nodes, stats, missed);
+            else hipLaunchKernelGGL((k_trace<true, false, true>), grid, block, 0, s, p, b, nodes, stats, missed);
         } else {
-            if (stats) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, s, p, b, nodes, stats);
-            else hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, s, p, b, nodes, stats);
+            if (stats) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, s, p, b, nodes, stats, missed);
+            else hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, s, p, b, nodes, stats, missed);
         }
         return rt_launch_status();
     }
 
-    rc = trace_workspace(dev, nr);
-    if (rc) return rc;
     RT_HIP(hipMemsetAsync(dev->queue_counter, 0, 1024, s));
+    // the traversal only leaves dead rays out where it walks the rays in a sorted order; otherwise it walks them all
+    // again (they miss again) and only the marks are kept
+    uint32_t* live = (missed && sort_rays) ? dev->queue_counter + 129 : nullptr;
     // persistent grid: enough workgroups to fill every CU, never more than there are rays to hand out
     uint32_t groups = (uint32_t)dev->compute_units * blocks_per_cu;
     if (groups > grid.x) groups = grid.x;
@@ -1477,7 +1529,8 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         key_nodes = on_spatial ? (const float4*)accel->sp_nodes : nodes;
         key_pairs = on_spatial ? (const float4*)accel->sp_pairs : pairs;
         hipLaunchKernelGGL(k_ray_keys, grid, block, 0, s, nr, ray_in, key_nodes, key_pairs, 1u << (depth - 1u), (nodes_there + 1u) / 2u,
-                           probe_stride, cost_shift, key_passes == 1u ? 8u : cost_bits, 8u * key_passes, dev->ray_keys_a);
+                           probe_stride, cost_shift, key_passes == 1u ? 8u : cost_bits, 8u * key_passes, dev->ray_keys_a,
+                           (const uint8_t*)(live ? missed : nullptr), live);
         rc = rt_sort_pairs(dev, dev->ray_keys_a, dev->ray_keys_b, nr, key_passes, &order);      // 8, 16 or 24-bit keys
         if (rc) return rc;
     }
@@ -1485,7 +1538,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     const size_t lds_bytes = ((size_t)kFifo * 512u + (stats ? (size_t)p.lv.count * 256u : 0u)) * sizeof(uint32_t);
 #define RT_LAUNCH_TRAVERSE(STATS, DIV)                                                                                         \
     hipLaunchKernelGGL((k_traverse<STATS, DIV>), dim3(groups), block, lds_bytes, s, p, ray_in, nodes, pairs, st, dev->hit_records, \
-                       dev->hit_ci, dev->queue_counter, order, stats)
+                       dev->hit_ci, dev->queue_counter, order, stats, (const uint32_t*)live)
     hipEvent_t* timing = nullptr;
     if (dev->time_traverse) {
         if (dev->timing_count == dev->timing_capacity) {      // grow the pool of event pairs
@@ -1517,7 +1570,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
                        (size_t)(kFifo * 512u + 4u * kStockFields * 64u) * sizeof(uint32_t), s, ps, ray_in,                      \
                        (const float4*)accel->sp_nodes, (const float4*)accel->sp_pairs, (const float4*)accel->sp_quads,          \
                        (const float4*)accel->sp_tris, dev->hit_records, dev->hit_ci, dev->queue_counter, order, st,            \
-                       (const uint32_t*)accel->ranks, dev->listed_rays, listed, dev->walk_stats)
+                       (const uint32_t*)accel->ranks, dev->listed_rays, listed, dev->walk_stats, (const uint32_t*)live)
         if (dev->walk_stats) RT_LAUNCH_SPATIAL(true);
         else RT_LAUNCH_SPATIAL(false);
 #undef RT_LAUNCH_SPATIAL
@@ -1526,7 +1579,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
                            (const uint32_t*)listed);
     } else if (quad_kernel && offsets_fit && p.lv.count >= 3u && quads)
         hipLaunchKernelGGL(k_traverse_quad, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in, nodes, pairs, quads,
-                           st, dev->hit_records, dev->hit_ci, dev->queue_counter, order, (const uint32_t*)nullptr);
+                           st, dev->hit_records, dev->hit_ci, dev->queue_counter, order, (const uint32_t*)live);
     else RT_LAUNCH_TRAVERSE(false, false);
 #undef RT_LAUNCH_TRAVERSE
     if (timing) {
@@ -1535,7 +1588,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     }
     rc = rt_launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_shade, grid, block, 0, s, p, b, (const float4*)dev->hit_records, (const uint32_t*)dev->hit_ci);
+    hipLaunchKernelGGL(k_shade, grid, block, 0, s, p, b, (const float4*)dev->hit_records, (const uint32_t*)dev->hit_ci, missed);
     return rt_launch_status();
 }
 
@@ -1558,6 +1611,13 @@ int rt_device_set_walk_stats(rt_device* dev, rt_buffer* stats) {
 int rt_device_set_trace_kernel(rt_device* dev, int kernel) {
     if (!dev || kernel < RT_TRACE_KERNEL_QUAD || kernel > RT_TRACE_KERNEL_SPATIAL) return RT_ERR_INVALID_ARGUMENT;
     dev->trace_kernel = kernel;
+    return RT_OK;
+}
+
+int rt_device_set_drop_missed_rays(rt_device* dev, int enable) {
+    if (!dev) return RT_ERR_INVALID_ARGUMENT;
+    dev->drop_missed = enable != 0;
+    dev->missed_valid = false;
     return RT_OK;
 }
 

@@ -23,6 +23,8 @@ struct rth_settings
 	uint32_t seed_raygen, seed_trace;
 	int32_t dynamic_scene;
 	int32_t reference_order_walk;
+	int32_t drop_missed_rays;
+	uint32_t device_rank, device_count;
 };
 
 void rth_camera_matrices(const float* position, const float* focus, const float* up, float fov, float aspect, float near_z, float far_z,
@@ -39,6 +41,12 @@ void rth_camera_matrices(const float* position, const float* focus, const float*
 float rth_parse_real(const char* text) { return ParseReal(text, text + std::strlen(text)); }
 
 // ---- meshes ----
+MeshInfo* rth_load_mesh_dedup(const char* path)
+{
+	MeshInfo m = LoadMeshFromFile(path, true);
+	if (!m.Vertices) return nullptr;
+	return new MeshInfo(m);
+}
 MeshInfo* rth_load_mesh(const char* path)
 {
 	MeshInfo m = LoadMeshFromFile(path);
@@ -111,6 +119,9 @@ static Settings ToSettings(const rth_settings* s)
 	r.SeedRayGen = s->seed_raygen; r.SeedTrace = s->seed_trace;
 	r.DynamicScene = s->dynamic_scene != 0;
 	r.ReferenceOrderWalk = s->reference_order_walk != 0;
+	r.DropMissedRays = s->drop_missed_rays != 0;
+	r.DeviceRank = s->device_rank;
+	r.DeviceCount = s->device_count ? s->device_count : 1;
 	return r;
 }
 
@@ -140,6 +151,8 @@ rt_buffer* rth_pipeline_slot(RaytracerPipeline* p, uint32_t slot) { return slot 
 int rth_pipeline_save_state(RaytracerPipeline* p, const char* path) { return p->SaveState(path) ? 1 : 0; }
 int rth_pipeline_load_state(RaytracerPipeline* p, const char* path) { return p->LoadState(path) ? 1 : 0; }
 uint32_t rth_pipeline_num_samples(RaytracerPipeline* p) { return p->GetNumSamples(); }
+uint32_t rth_pipeline_local_rows(RaytracerPipeline* p) { return p->GetLocalRows(); }
+int rth_pipeline_gather_output(RaytracerPipeline* p, rt_comm* comm, rt_buffer* image) { return p->GatherOutput(comm, image) ? 1 : 0; }
 void rth_pipeline_destroy(RaytracerPipeline* p) { delete p; }
 
 int rth_write_ppm(const char* path, const float* pixels, uint32_t w, uint32_t h) { return WriteImagePPM(path, pixels, w, h) ? 1 : 0; }

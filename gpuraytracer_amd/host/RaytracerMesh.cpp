@@ -485,7 +485,53 @@ namespace RT::GraphicsAPI
 	}
 
 
-	MeshInfo LoadMeshFromFile(const std::string& sFileName)
+	//Removal of vertex duplicates with the semantics of the loop the reference has switched off
+	//(src/RaytracerMesh.cpp:249-275 of the reference): vertex i gets the index of the first earlier unique vertex that
+	//VerticesAreEqual (:157-169: position, UV, normal, material; tangents are not compared - they are computed later)
+	//accepts, or becomes a new unique vertex. Equality of floats makes -0 equal +0 and a NaN unequal to everything, so the
+	//hash key holds the components with -0 turned into +0, and a vertex with a NaN is always unique. Expected O(n)
+	//instead of the reference's O(n^2).
+	static uint64_t DeduplicateVertices(const std::vector<Vertex>& stdVertices, Index* rtIndices, std::vector<Vertex>& stdUnique)
+	{
+		struct Key { uint32_t w[9]; bool operator==(const Key& o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; } };
+		struct KeyHash
+		{
+			size_t operator()(const Key& k) const
+			{
+				uint64_t h = 0xcbf29ce484222325ull;
+				for (uint32_t x : k.w) { h ^= x; h *= 0x100000001b3ull; h ^= h >> 29; }
+				return (size_t)h;
+			}
+		};
+		std::unordered_map<Key, Index, KeyHash> stdFirst;
+		stdFirst.reserve(stdVertices.size());
+		stdUnique.clear();
+		for (size_t i = 0; i < stdVertices.size(); i++)
+		{
+			const Vertex& v = stdVertices[i];
+			const float f[8] = { v.Position.x, v.Position.y, v.Position.z, v.UV.x, v.UV.y, v.Normal.x, v.Normal.y, v.Normal.z };
+			Key k;
+			bool bNaN = false;
+			for (int c = 0; c < 8; c++)
+			{
+				const float x = f[c] == 0.0f ? 0.0f : f[c];		//-0 -> +0
+				bNaN = bNaN || x != x;
+				std::memcpy(&k.w[c], &x, 4);
+			}
+			k.w[8] = v.MaterialID;
+			if (!bNaN)
+			{
+				auto [stdIt, bNew] = stdFirst.try_emplace(k, (Index)stdUnique.size());
+				if (!bNew) { rtIndices[i] = stdIt->second; continue; }
+			}
+			rtIndices[i] = (Index)stdUnique.size();
+			stdUnique.push_back(v);
+		}
+		return stdUnique.size();
+	}
+
+
+	MeshInfo LoadMeshFromFile(const std::string& sFileName, bool bDeduplicate)
 	{
 		MeshInfo rtNothing{};
 		std::ifstream stdFile(sFileName);
@@ -581,13 +627,23 @@ namespace RT::GraphicsAPI
 			return rtNothing;
 		}
 
-		//no duplicate removal (the reference has it switched off): Indices[i] == i
+		//no duplicate removal by default (the reference has it switched off): Indices[i] == i
 		MeshInfo rtMesh{};
 		rtMesh.IndexCount = iNumVertices;
 		rtMesh.Indices = new Index[iNumVertices];
-		rtMesh.VertexCount = iNumVertices;
-		rtMesh.Vertices = new Vertex[iNumVertices];
-		for (uint64_t i = 0; i < iNumVertices; i++) { rtMesh.Indices[i] = (Index)i; rtMesh.Vertices[i] = stdVertices[i]; }
+		if (bDeduplicate)
+		{
+			std::vector<Vertex> stdUnique;
+			rtMesh.VertexCount = DeduplicateVertices(stdVertices, rtMesh.Indices, stdUnique);
+			rtMesh.Vertices = new Vertex[rtMesh.VertexCount];
+			for (uint64_t i = 0; i < rtMesh.VertexCount; i++) rtMesh.Vertices[i] = stdUnique[i];
+		}
+		else
+		{
+			rtMesh.VertexCount = iNumVertices;
+			rtMesh.Vertices = new Vertex[iNumVertices];
+			for (uint64_t i = 0; i < iNumVertices; i++) { rtMesh.Indices[i] = (Index)i; rtMesh.Vertices[i] = stdVertices[i]; }
+		}
 
 		//materials (src/RaytracerMesh.cpp:277-321 of the reference)
 		const uint64_t iNumMaterials = stdMaterials.size();

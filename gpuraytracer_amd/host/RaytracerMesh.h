@@ -76,7 +76,10 @@ namespace RT::GraphicsAPI
 	//replicating the byte). A failed load returns a TextureInfo of zeros.
 	TextureInfo LoadTextureFromFile(const std::string& sFileName, int iDesiredNumChannels = 4, bool bHighPrecision = true);
 	//Wavefront OBJ + MTL. A failed load returns a MeshInfo of zeros. Only triangle faces are accepted.
-	MeshInfo LoadMeshFromFile(const std::string& sFileName);
+	//bDeduplicate: equal vertices (position, UV, normal and material, compared as the reference's VerticesAreEqual does,
+	//src/RaytracerMesh.cpp:157-169 of the reference) are stored once and shared through the index buffer - the loop the
+	//reference has commented out as too slow (src/RaytracerMesh.cpp:249-275), done with a hash table. Default: off, as there.
+	MeshInfo LoadMeshFromFile(const std::string& sFileName, bool bDeduplicate = false);
 	//frees the host arrays of a MeshInfo that was not handed to RaytracerMesh::Initialize
 	void ReleaseMeshInfo(MeshInfo& rtMesh);
 

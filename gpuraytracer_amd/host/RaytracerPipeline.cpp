@@ -110,6 +110,12 @@ namespace RT::GraphicsAPI
 		}
 
 		uint32_t SeedOrRandom(uint32_t iSeed) { return iSeed ? iSeed : (uint32_t)s_stdSeedGenerator(); }
+
+		//the image rows of this device: every DeviceCount-th row from row DeviceRank on
+		bool RowsOfDevice(const Settings& rtSettings, rt_image_rows* rtRows)
+		{
+			return rt_rows_for_rank(rtSettings.WindowHeight, rtSettings.DeviceCount, rtSettings.DeviceRank, rtRows) == RT_OK;
+		}
 	}
 
 
@@ -131,6 +137,7 @@ namespace RT::GraphicsAPI
 		m_rtRayBuffer(nullptr),
 		m_rtOldRayBuffer(nullptr),
 		m_rtRayPixelsBuffer(nullptr),
+		m_rtRows(),
 		m_stdPRNG()
 	{
 	}
@@ -148,9 +155,10 @@ namespace RT::GraphicsAPI
 		m_rtUAVDescriptorHeap = rtUAVDescriptorTable;
 		if (!m_rtDevice || !m_rtUAVDescriptorHeap) return false;
 		m_stdPRNG.seed(SeedOrRandom(rtSettings.SeedRayGen));
+		if (!RowsOfDevice(rtSettings, &m_rtRows)) return false;
 
 		//ray, previous-ray and pixel-coordinate buffers (u0, u1, u2)
-		const size_t iMaxRays = (size_t)rtSettings.WindowWidth * rtSettings.WindowHeight * rtSettings.MaxRaysPerPixel;
+		const size_t iMaxRays = (size_t)rtSettings.WindowWidth * m_rtRows.num_rows * rtSettings.MaxRaysPerPixel;
 		if (rt_buffer_alloc(m_rtDevice, SIZEOF_RAY * iMaxRays, &m_rtRayBuffer) != RT_OK) return false;
 		if (rt_buffer_alloc(m_rtDevice, SIZEOF_RAY * iMaxRays, &m_rtOldRayBuffer) != RT_OK) return false;
 		if (rt_buffer_alloc(m_rtDevice, SIZEOF_RAYPIXEL * iMaxRays, &m_rtRayPixelsBuffer) != RT_OK) return false;
@@ -175,7 +183,7 @@ namespace RT::GraphicsAPI
 		m_rtInfoData.rng_seed[0] = (uint32_t)m_stdPRNG();
 		m_rtInfoData.rng_seed[1] = (uint32_t)m_stdPRNG();
 		m_rtInfoData.rng_seed[2] = (uint32_t)m_stdPRNG();
-		return rt_camera_ray_generation(m_rtDevice, &m_rtInfoData, m_rtRayBuffer, m_rtOldRayBuffer, m_rtRayPixelsBuffer, nullptr) == RT_OK;
+		return rt_camera_ray_generation(m_rtDevice, &m_rtInfoData, m_rtRayBuffer, m_rtOldRayBuffer, m_rtRayPixelsBuffer, &m_rtRows) == RT_OK;
 	}
 
 
@@ -351,6 +359,7 @@ namespace RT::GraphicsAPI
 		m_rtMaterialBuffer(nullptr),
 		m_rtScatteredLightBuffer(nullptr),
 		m_rtEmittedLightBuffer(nullptr),
+		m_rtRows(),
 		m_stdPRNG(),
 		m_bUseBVH(true)
 	{
@@ -372,9 +381,10 @@ namespace RT::GraphicsAPI
 		if (!m_rtDevice || !m_rtUAVDescriptorHeap || !rtMeshData.Materials) return false;
 		m_stdPRNG.seed(SeedOrRandom(rtSettings.SeedTrace));
 		m_bUseBVH = rtSettings.UseBVH;
+		if (!RowsOfDevice(rtSettings, &m_rtRows)) return false;
 
 		//materials (t2) and the two per-ray light buffers (u3, u4)
-		const size_t iMaxRays = (size_t)rtSettings.WindowWidth * rtSettings.WindowHeight * rtSettings.MaxRaysPerPixel;
+		const size_t iMaxRays = (size_t)rtSettings.WindowWidth * m_rtRows.num_rows * rtSettings.MaxRaysPerPixel;
 		if (rt_buffer_alloc(m_rtDevice, sizeof(PBRMaterial) * rtMeshData.MaterialCount, &m_rtMaterialBuffer) != RT_OK) return false;
 		if (rt_buffer_upload(m_rtMaterialBuffer, rtMeshData.Materials, sizeof(PBRMaterial) * rtMeshData.MaterialCount, 0) != RT_OK) return false;
 		if (rt_buffer_alloc(m_rtDevice, 16 * iMaxRays, &m_rtScatteredLightBuffer) != RT_OK) return false;
@@ -422,9 +432,9 @@ namespace RT::GraphicsAPI
 		rt_buffer** rtSlots = m_rtUAVDescriptorHeap->Slots;
 		if (m_bUseBVH && rtAccel)
 			return rt_trace_rays_accel(m_rtDevice, &m_rtInfoData, rtAccel, rtIndices, rtVertices, m_rtMaterialBuffer, rtTextureIDs, rtAtlas, iAtlasElements,
-				rtSlots[0], rtSlots[1], rtSlots[2], rtSlots[3], rtSlots[4], rtBVH, nullptr) == RT_OK;
+				rtSlots[0], rtSlots[1], rtSlots[2], rtSlots[3], rtSlots[4], rtBVH, &m_rtRows) == RT_OK;
 		return rt_trace_rays(m_rtDevice, &m_rtInfoData, m_bUseBVH ? 1 : 0, rtIndices, rtVertices, m_rtMaterialBuffer, rtTextureIDs, rtAtlas, iAtlasElements,
-			rtSlots[0], rtSlots[1], rtSlots[2], rtSlots[3], rtSlots[4], rtBVH, nullptr) == RT_OK;
+			rtSlots[0], rtSlots[1], rtSlots[2], rtSlots[3], rtSlots[4], rtBVH, &m_rtRows) == RT_OK;
 	}
 
 
@@ -450,7 +460,9 @@ namespace RT::GraphicsAPI
 		m_rtDevice = rtDevice;
 		m_rtUAVDescriptorHeap = rtUAVDescriptorTable;
 		if (!m_rtDevice || !m_rtUAVDescriptorHeap) return false;
-		const size_t iPixels = (size_t)rtSettings.WindowWidth * rtSettings.WindowHeight;
+		rt_image_rows rtRows;
+		if (!RowsOfDevice(rtSettings, &rtRows)) return false;
+		const size_t iPixels = (size_t)rtSettings.WindowWidth * rtRows.num_rows;
 		//the running mean (u5) and the tone-mapped output (u6, the reference's RGBA16F texture kept in binary32)
 		if (rt_buffer_alloc(m_rtDevice, 16 * iPixels, &m_rtResultBuffer) != RT_OK) return false;
 		if (rt_buffer_alloc(m_rtDevice, 16 * iPixels, &m_rtOutputTexture) != RT_OK) return false;
@@ -458,7 +470,7 @@ namespace RT::GraphicsAPI
 		m_rtUAVDescriptorHeap->Slots[6] = m_rtOutputTexture;
 
 		m_rtInfoData.screen_dimensions[0] = (int32_t)rtSettings.WindowWidth;
-		m_rtInfoData.screen_dimensions[1] = (int32_t)rtSettings.WindowHeight;
+		m_rtInfoData.screen_dimensions[1] = (int32_t)rtRows.num_rows;		//the rows the buffers hold
 		m_rtInfoData.max_rays_per_pixel = rtSettings.MaxRaysPerPixel;
 		m_rtInfoData.num_samples = 1;
 		return true;
@@ -496,7 +508,8 @@ namespace RT::GraphicsAPI
 		m_iIteration(0),
 		m_rtBaseVertexBuffer(nullptr),
 		m_rtBoundsBuffer(nullptr),
-		m_iFrame(0)
+		m_iFrame(0),
+		m_rtRows()
 	{
 	}
 
@@ -519,8 +532,10 @@ namespace RT::GraphicsAPI
 		if (!m_rtDevice) return false;
 		if (rtSettings) m_rtSettings = *rtSettings;
 		if (m_rtSettings.MaxRayDepth == 0 || m_rtSettings.MaxRaysPerPixel == 0) return false;
+		if (!RowsOfDevice(m_rtSettings, &m_rtRows)) return false;
 		if (rt_device_set_trace_kernel(m_rtDevice, m_rtSettings.ReferenceOrderWalk ? RT_TRACE_KERNEL_QUAD : RT_TRACE_KERNEL_SPATIAL) != RT_OK)
 			return false;
+		if (rt_device_set_drop_missed_rays(m_rtDevice, m_rtSettings.DropMissedRays ? 1 : 0) != RT_OK) return false;
 		m_rtSceneAABB = rtMeshData.SceneAABB;
 		if (m_rtSettings.DynamicScene)
 		{
@@ -626,9 +641,15 @@ namespace RT::GraphicsAPI
 		return true;
 	}
 
+	bool RaytracerPipeline::GatherOutput(rt_comm* rtComm, rt_buffer* rtImage)
+	{
+		if (!rtComm || rt_comm_world(rtComm) != (int)m_rtSettings.DeviceCount || rt_comm_rank(rtComm) != (int)m_rtSettings.DeviceRank) return false;
+		return rt_gather_rows(rtComm, m_rtUAVDescriptorHeap->Slots[6], m_rtSettings.WindowWidth, m_rtSettings.WindowHeight, 0, rtImage) == RT_OK;
+	}
+
 	bool RaytracerPipeline::ReadOutput(float* pPixels)
 	{
-		const size_t iBytes = 16 * (size_t)m_rtSettings.WindowWidth * m_rtSettings.WindowHeight;
+		const size_t iBytes = 16 * (size_t)m_rtSettings.WindowWidth * m_rtRows.num_rows;
 		return rt_buffer_readback(m_rtUAVDescriptorHeap->Slots[6], pPixels, iBytes, 0) == RT_OK;
 	}
 
@@ -636,7 +657,7 @@ namespace RT::GraphicsAPI
 	//(one line each: ray generation, tracing), then width * height float4 (little-endian binary32)
 	bool RaytracerPipeline::SaveState(const std::string& sFileName)
 	{
-		if (m_iIteration != 0) return false;		//only between two sample cycles
+		if (m_iIteration != 0 || m_rtSettings.DeviceCount != 1) return false;		//only between two sample cycles, of a whole image
 		const size_t iPixels = (size_t)m_rtSettings.WindowWidth * m_rtSettings.WindowHeight;
 		std::vector<float> stdPixels(iPixels * 4);
 		if (!ReadResult(stdPixels.data())) return false;
@@ -651,7 +672,7 @@ namespace RT::GraphicsAPI
 
 	bool RaytracerPipeline::LoadState(const std::string& sFileName)
 	{
-		if (m_iIteration != 0) return false;
+		if (m_iIteration != 0 || m_rtSettings.DeviceCount != 1) return false;
 		std::ifstream stdFile(sFileName, std::ios::binary);
 		if (!stdFile) return false;
 		std::string sMagic;
@@ -676,7 +697,7 @@ namespace RT::GraphicsAPI
 
 	bool RaytracerPipeline::ReadResult(float* pPixels)
 	{
-		const size_t iBytes = 16 * (size_t)m_rtSettings.WindowWidth * m_rtSettings.WindowHeight;
+		const size_t iBytes = 16 * (size_t)m_rtSettings.WindowWidth * m_rtRows.num_rows;
 		return rt_buffer_readback(m_rtUAVDescriptorHeap->Slots[5], pPixels, iBytes, 0) == RT_OK;
 	}
 

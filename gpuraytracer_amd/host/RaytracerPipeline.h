@@ -58,6 +58,7 @@ namespace RT::GraphicsAPI
 		rt_buffer* m_rtRayBuffer;
 		rt_buffer* m_rtOldRayBuffer;
 		rt_buffer* m_rtRayPixelsBuffer;
+		rt_image_rows m_rtRows;
 		std::mt19937 m_stdPRNG;
 
 	public:
@@ -142,6 +143,7 @@ namespace RT::GraphicsAPI
 		rt_buffer* m_rtMaterialBuffer;
 		rt_buffer* m_rtScatteredLightBuffer;
 		rt_buffer* m_rtEmittedLightBuffer;
+		rt_image_rows m_rtRows;
 		std::mt19937 m_stdPRNG;
 		bool m_bUseBVH;
 
@@ -199,6 +201,7 @@ namespace RT::GraphicsAPI
 		rt_buffer*				m_rtBaseVertexBuffer;	//DynamicScene: the mesh as loaded
 		rt_buffer*				m_rtBoundsBuffer;		//DynamicScene: centroid bounds of the moved mesh (device)
 		uint32_t				m_iFrame;
+		rt_image_rows			m_rtRows;				//the image rows this device renders
 
 		bool MoveScene();
 
@@ -210,9 +213,14 @@ namespace RT::GraphicsAPI
 		bool Initialize(rt_device* rtDevice, MeshInfo rtMeshData, const Settings* rtSettings = nullptr);
 		bool Render();
 
-		//headless output instead of the window: the tone-mapped image and the accumulated mean, Width * Height float4 each
+		//headless output instead of the window: the tone-mapped image and the accumulated mean, float4 per pixel of the
+		//rows this pipeline holds (GetLocalRows() x Width; the whole image on a single device)
 		bool ReadOutput(float* pPixels);
 		bool ReadResult(float* pPixels);
+		uint32_t GetLocalRows() const { return m_rtRows.num_rows; };
+		//multi-GPU: collective over the pipelines of all devices - the tone-mapped rows travel to rank 0 (RCCL), whose
+		//rtImage (Width * Height float4, device memory; null elsewhere) receives the image
+		bool GatherOutput(rt_comm* rtComm, rt_buffer* rtImage);
 		//checkpoint of the accumulation (the reference has none: its state lives in ResultBuffer, NumSamples and its two
 		//host generators): the running-mean image, the sample counter, both std::mt19937 states and the frame of a moving
 		//scene, written / restored between two sample cycles, so that k cycles + resume + k cycles = 2k cycles

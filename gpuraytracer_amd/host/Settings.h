@@ -59,6 +59,11 @@ namespace RT
 		                                    //device (rt_synthetic_animate), the scene bounds reduced there and the tree rebuilt
 		bool ReferenceOrderWalk = false;    //trace by the walk of the reference's hierarchy in the reference's order
 		                                    //(RT_TRACE_KERNEL_QUAD) instead of the default on the library's own hierarchy
+		bool DropMissedRays = false;        //leave rays that have missed out of the later bounces of their sample cycle instead of
+		                                    //tracing them again as the reference does (same image, less work; rt_device_set_drop_missed_rays)
+		bool DeduplicateVertices = false;   //LoadMeshFromFile merges equal vertices (the loop the reference has switched off)
+		uint32_t DeviceRank = 0;            //multi-GPU: this pipeline renders the image rows DeviceRank, DeviceRank + DeviceCount, ...
+		uint32_t DeviceCount = 1;           //(one pipeline per GPU, same scene and seeds on each; RaytracerPipeline::GatherOutput assembles the image)
 		uint32_t SeedRayGen = 0;            //std::mt19937 seeds of the two host generators; 0 = std::random_device
 		uint32_t SeedTrace = 0;
 	};

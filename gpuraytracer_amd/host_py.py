@@ -17,7 +17,8 @@ class HostSettings(C.Structure):
                 ("near_z", C.c_float), ("far_z", C.c_float), ("cam_position", C.c_float * 3), ("cam_focus", C.c_float * 3),
                 ("cam_up", C.c_float * 3), ("rebuild_every_cycle", C.c_int32), ("fused_build", C.c_int32),
                 ("seed_raygen", C.c_uint32), ("seed_trace", C.c_uint32), ("dynamic_scene", C.c_int32),
-                ("reference_order_walk", C.c_int32)]
+                ("reference_order_walk", C.c_int32), ("drop_missed_rays", C.c_int32), ("device_rank", C.c_uint32),
+                ("device_count", C.c_uint32)]
 
 
 _P = C.c_void_p
@@ -37,6 +38,7 @@ def load():
         "rth_camera_matrices": (None, [f3, f3, f3, C.c_float, C.c_float, C.c_float, C.c_float, f3, f3]),
         "rth_parse_real": (C.c_float, [C.c_char_p]),
         "rth_load_mesh": (_P, [C.c_char_p]),
+        "rth_load_mesh_dedup": (_P, [C.c_char_p]),
         "rth_synthetic_scene": (_P, [C.c_uint32, C.c_uint32]),
         "rth_mesh_index_count": (C.c_uint64, [_P]), "rth_mesh_vertex_count": (C.c_uint64, [_P]),
         "rth_mesh_material_count": (C.c_uint64, [_P]), "rth_mesh_texture_count": (C.c_uint64, [_P]),
@@ -52,6 +54,8 @@ def load():
         "rth_pipeline_bvh": (_P, [_P]), "rth_pipeline_morton": (_P, [_P]), "rth_pipeline_slot": (_P, [_P, C.c_uint32]),
         "rth_pipeline_save_state": (C.c_int, [_P, C.c_char_p]), "rth_pipeline_load_state": (C.c_int, [_P, C.c_char_p]),
         "rth_pipeline_num_samples": (C.c_uint32, [_P]),
+        "rth_pipeline_local_rows": (C.c_uint32, [_P]),
+        "rth_pipeline_gather_output": (C.c_int, [_P, _P, _P]),
         "rth_pipeline_destroy": (None, [_P]),
         "rth_write_ppm": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
         "rth_write_pfm": (C.c_int, [C.c_char_p, _P, C.c_uint32, C.c_uint32]),
@@ -100,10 +104,11 @@ def _mesh_to_scene(lib, h, texture_prefix="", camera=None, name=""):
                 camera=camera, name=name)
 
 
-def load_scene(obj_path, texture_prefix="", camera=None):
-    """LoadMeshFromFile + TextureAtlas packing through the C++ host; returns a scene dict."""
+def load_scene(obj_path, texture_prefix="", camera=None, dedup=False):
+    """LoadMeshFromFile + TextureAtlas packing through the C++ host; returns a scene dict. dedup: equal vertices are
+    merged (LoadMeshFromFile's bDeduplicate)."""
     lib = load()
-    h = lib.rth_load_mesh(obj_path.encode())
+    h = (lib.rth_load_mesh_dedup if dedup else lib.rth_load_mesh)(obj_path.encode())
     if not h:
         raise RuntimeError("LoadMeshFromFile failed for %s" % obj_path)
     try:
@@ -151,10 +156,12 @@ class HostPipeline:
     """RaytracerPipeline (C++) driven from Python: Initialize once, Render() per bounce."""
 
     def __init__(self, dev, mesh_source, width, height, camera, rpp=1, depth=3, aa=1.5, dof=0.0, use_bvh=True, fused_build=True,
-                 rebuild_every_cycle=False, seed_raygen=1, seed_trace=2, dynamic=False, reference_order_walk=False):
+                 rebuild_every_cycle=False, seed_raygen=1, seed_trace=2, dynamic=False, reference_order_walk=False,
+                 drop_missed_rays=False, device_rank=0, device_count=1):
         self.lib = load()
         self.dev = dev
         self.width, self.height = width, height
+        self.local_rows = max(0, (height - device_rank + device_count - 1) // device_count)
         if isinstance(mesh_source, int):
             mesh = self.lib.rth_synthetic_scene(mesh_source, 12345)
         else:
@@ -173,6 +180,8 @@ class HostPipeline:
         s.seed_raygen, s.seed_trace = seed_raygen, seed_trace
         s.dynamic_scene = int(dynamic)
         s.reference_order_walk = int(reference_order_walk)
+        s.drop_missed_rays = int(drop_missed_rays)
+        s.device_rank, s.device_count = int(device_rank), int(device_count)
         self.handle = self.lib.rth_pipeline_create(dev.handle, mesh, C.byref(s))
         if not self.handle:
             raise RuntimeError("RaytracerPipeline::Initialize failed")
@@ -181,14 +190,19 @@ class HostPipeline:
         if not self.lib.rth_pipeline_render(self.handle, calls):
             raise RuntimeError("RaytracerPipeline::Render failed")
 
+    def gather_output(self, comm, image):
+        """RaytracerPipeline::GatherOutput: collective; comm is an rt_comm handle, image an rt_buffer handle (rank 0) or None."""
+        if not self.lib.rth_pipeline_gather_output(self.handle, comm, image):
+            raise RuntimeError("GatherOutput failed")
+
     def output(self):
-        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        out = np.zeros((self.local_rows, self.width, 4), dtype=np.float32)
         if not self.lib.rth_pipeline_read_output(self.handle, out.ctypes.data_as(_P)):
             raise RuntimeError("ReadOutput failed")
         return out
 
     def result(self):
-        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        out = np.zeros((self.local_rows, self.width, 4), dtype=np.float32)
         if not self.lib.rth_pipeline_read_result(self.handle, out.ctypes.data_as(_P)):
             raise RuntimeError("ReadResult failed")
         return out

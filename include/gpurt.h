@@ -31,12 +31,15 @@ extern "C" {
 #define RT_ERR_BUFFER_TOO_SMALL 3
 #define RT_ERR_OUT_OF_MEMORY 4
 #define RT_ERR_LIMIT_EXCEEDED 5     /* beyond the fixed limit of an entry point that allocates nothing */
+#define RT_ERR_RCCL_UNAVAILABLE 6   /* librccl.so.1 could not be loaded (multi-GPU entry points only) */
 #define RT_ERR_HIP_BASE 0x1000      /* 0x1000 + hipError_t */
+#define RT_ERR_RCCL_BASE 0x2000     /* 0x2000 + ncclResult_t */
 
 typedef struct rt_device rt_device;
 typedef struct rt_buffer rt_buffer;
 typedef struct rt_event rt_event;
 typedef struct rt_accel rt_accel;
+typedef struct rt_comm rt_comm;
 
 /* ---- element layouts (shader/Raytracer.hlsli:15-40, src/RaytracerMesh.h:14-46,
  *      shader/PerRayShading.hlsli:27-48, src/TextureAtlas.h:14-20) ---- */
@@ -102,6 +105,15 @@ int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats);
 #define RT_TRACE_KERNEL_SIMPLE 2
 #define RT_TRACE_KERNEL_SPATIAL 3
 int rt_device_set_trace_kernel(rt_device* dev, int kernel);
+/* Dropping missed rays between bounces (no counterpart call in the reference; its author's notes on re-binning rays are
+ * at shader/CS_Intersection.hlsl:20-37). In the reference a ray that misses is left untouched (shader/CS_TraceRays.hlsl:248,
+ * 290-291) and is traced again, unchanged, by every later bounce of the sample cycle - to miss again. While enabled, the
+ * shading step marks such rays and later trace calls leave them out (their place in the ray order goes to the end and
+ * the traversal launches over the live rays only) until new camera rays are generated or a hierarchy is built on this
+ * device. For a scene that does not change inside a sample cycle every buffer stays bit-identical to the default mode;
+ * the difference is work, not results. The marks follow the device's own calls: after changing the ray buffers by other
+ * means (rt_buffer_upload), call this function again to clear them. Default: off, the reference's re-tracing. */
+int rt_device_set_drop_missed_rays(rt_device* dev, int enable);
 /* The slab test as the reference writes it (no counterpart call in the reference; it selects the reference's own
  * arithmetic): shader/CS_TraceRays.hlsl:83-84 divides by the ray direction for every box, the kernels above multiply by
  * one reciprocal per ray and axis, which rounds differently in the last place and lets a few rays per million enter or
@@ -270,6 +282,32 @@ int rt_trace_rays_accel(rt_device* dev, const rt_trace_rays_info* info, const rt
                         const rt_buffer* texture_atlas, uint32_t atlas_elements, rt_buffer* rays, rt_buffer* old_rays,
                         const rt_buffer* ray_pixels, rt_buffer* scattered_light, rt_buffer* emitted_light,
                         const rt_buffer* bvh, const rt_image_rows* rows);
+
+/* ---- multi-GPU (no counterpart in the reference, which renders on one device): one process or host thread per GPU,
+ *      the image rows dealt to the devices in turn, scene and hierarchy replicated and rebuilt per device, and ONE
+ *      exchange per finished frame - the rows gathered to a root device over RCCL (xGMI inside a node). RCCL is loaded
+ *      at run time by the first of these calls; nothing else in the library needs it. ---- */
+/* The rows rank `rank` of `world` holds: rank, rank + world, ... ({first_row, num_rows, row_stride = world}; pass it to
+ * rt_camera_ray_generation / rt_trace_rays). A rank beyond the image height holds no row. */
+int rt_rows_for_rank(uint32_t height, uint32_t world, uint32_t rank, rt_image_rows* rows);
+/* gathered: float4 per pixel, the ranks' rows one rank after the other (what a gather of the per-rank row buffers
+ * yields); image: the same rows in image order. Not in place. */
+int rt_rows_interleave(rt_device* dev, const rt_buffer* gathered, uint32_t width, uint32_t height, uint32_t world, rt_buffer* image);
+#define RT_COMM_ID_BYTES 128
+/* An id for a new group of devices (ncclGetUniqueId): made once, by any one rank, and handed to every rank by the
+ * caller's own means (shared memory between threads, a file, the launcher's store). */
+int rt_comm_unique_id(void* unique_id /* RT_COMM_ID_BYTES */);
+/* Joins the group as rank `rank` of `world` with the device's GPU (ncclCommInitRank): collective, returns once every
+ * rank has called. One GPU can be one rank of a group only. */
+int rt_comm_init(rt_device* dev, int rank, int world, const void* unique_id, rt_comm** out);
+int rt_comm_destroy(rt_comm* comm);
+int rt_comm_rank(const rt_comm* comm);
+int rt_comm_world(const rt_comm* comm);
+/* Collective, queued on every rank's device stream: each rank's finished rows (float4 per pixel, the rows of
+ * rt_rows_for_rank one after the other - e.g. the output of rt_generate_final_image) travel to rank `root`, whose
+ * `image` (float4[width * height]; ignored elsewhere, may be NULL) receives them in image order. The root keeps a
+ * staging buffer of the image's size, allocated on the first call. */
+int rt_gather_rows(rt_comm* comm, const rt_buffer* rows, uint32_t width, uint32_t height, int root, rt_buffer* image);
 
 #ifdef __cplusplus
 }

@@ -478,3 +478,182 @@ def test_resume_continues_the_random_sequences(device, oracle, tmp_path):
         assert b.num_samples() == want_samples == 2 * k + 1
         assert b.result().view(np.uint32).tobytes() == want.view(np.uint32).tobytes(), "resumed run differs (dynamic=%s)" % dynamic
         b.close()
+
+
+# ------------------------------------------------------------------ multi-GPU entry points of the C-ABI ----
+
+@pytest.mark.parametrize("world,w,h", [(1, 33, 9), (2, 64, 36), (3, 50, 31), (8, 130, 67), (16, 7, 5)])
+def test_rows_interleave_puts_gathered_rows_in_image_order(device, world, w, h):
+    """rt_rows_interleave: the ranks' rows one rank after the other (what the gather delivers) -> rows in image order."""
+    from gpuraytracer_amd import capi
+    rng = np.random.RandomState(world)
+    image = rng.uniform(0, 1, (h, w, 4)).astype(np.float32)
+    gathered = np.concatenate([image[r::world] for r in range(world)], axis=0)
+    src, dst = device.upload(gathered), device.alloc(16 * w * h)
+    capi.check(device.lib.rt_rows_interleave(device.handle, src.handle, w, h, world, dst.handle), "rt_rows_interleave")
+    device.sync()
+    assert dst.download(np.float32, 4 * w * h).tobytes() == image.tobytes()
+    assert device.lib.rt_rows_interleave(device.handle, src.handle, w, h, 0, dst.handle) == capi.RT_ERR_INVALID_ARGUMENT
+    assert device.lib.rt_rows_interleave(device.handle, src.handle, w, h, world, src.handle) == capi.RT_ERR_INVALID_ARGUMENT
+    small = device.alloc(16)
+    assert device.lib.rt_rows_interleave(device.handle, src.handle, w, h, world, small.handle) == capi.RT_ERR_BUFFER_TOO_SMALL
+    for b in (src, dst, small):
+        b.free()
+
+
+def test_gather_rows_over_rccl_with_one_rank(device, oracle):
+    """rt_comm_unique_id / rt_comm_init / rt_gather_rows through RCCL itself with the one GPU a test box has: the rank
+    sends its rows to itself (an RCCL send/receive pair) and the root puts them in image order. Also through
+    RaytracerPipeline::GatherOutput of the C++ host."""
+    from gpuraytracer_amd import capi, host_py, scenes
+    lib = device.lib
+    uid = (C.c_ubyte * capi.RT_COMM_ID_BYTES)()
+    capi.check(lib.rt_comm_unique_id(uid), "rt_comm_unique_id")
+    comm = C.c_void_p()
+    capi.check(lib.rt_comm_init(device.handle, 0, 1, uid, C.byref(comm)), "rt_comm_init")
+    assert lib.rt_comm_rank(comm) == 0 and lib.rt_comm_world(comm) == 1
+    w, h = 96, 54
+    rows = np.random.RandomState(3).uniform(0, 1, (h, w, 4)).astype(np.float32)
+    src, dst = device.upload(rows), device.alloc(16 * w * h)
+    capi.check(lib.rt_gather_rows(comm, src.handle, w, h, 0, dst.handle), "rt_gather_rows")
+    device.sync()
+    assert dst.download(np.float32, 4 * w * h).tobytes() == rows.tobytes()
+    assert lib.rt_gather_rows(comm, src.handle, w, h, 1, dst.handle) == capi.RT_ERR_INVALID_ARGUMENT      # no such root
+    assert lib.rt_gather_rows(comm, src.handle, w, h, 0, None) == capi.RT_ERR_INVALID_ARGUMENT            # the root needs an image
+    n = 3000
+    hp = host_py.HostPipeline(device, n, w, h, scenes.synthetic_scene(n)["camera"], seed_raygen=1, seed_trace=2, device_rank=0, device_count=1)
+    hp.render(3)
+    hp.gather_output(comm, dst.handle)
+    device.sync()
+    assert dst.download(np.float32, 4 * w * h).tobytes() == hp.output().tobytes()
+    hp.close()
+    capi.check(lib.rt_comm_destroy(comm), "rt_comm_destroy")
+    bad = C.c_void_p()
+    assert lib.rt_comm_init(device.handle, 2, 2, uid, C.byref(bad)) == capi.RT_ERR_INVALID_ARGUMENT
+    for b in (src, dst):
+        b.free()
+
+
+def test_host_pipelines_of_three_ranks_assemble_to_the_whole_image(device, oracle):
+    """Settings::DeviceRank / DeviceCount of the C++ host: three RaytracerPipelines that hold the rows r, r + 3, ... of
+    the image (same scene, same seeds), their outputs one after the other and rt_rows_interleave = the single-device image."""
+    from gpuraytracer_amd import capi, host_py, scenes
+    n, w, h, depth, world = 5000, 80, 47, 3, 3
+    cam = scenes.synthetic_scene(n)["camera"]
+    whole = host_py.HostPipeline(device, n, w, h, cam, seed_raygen=1, seed_trace=2)
+    whole.render(2 * depth)
+    want = whole.output()
+    whole.close()
+    parts = []
+    for r in range(world):
+        hp = host_py.HostPipeline(device, n, w, h, cam, seed_raygen=1, seed_trace=2, device_rank=r, device_count=world)
+        hp.render(2 * depth)
+        parts.append(hp.output())
+        assert parts[-1].shape[0] == len(range(r, h, world))
+        hp.close()
+    src, dst = device.upload(np.concatenate(parts, axis=0)), device.alloc(16 * w * h)
+    capi.check(device.lib.rt_rows_interleave(device.handle, src.handle, w, h, world, dst.handle), "rt_rows_interleave")
+    device.sync()
+    assert dst.download(np.float32, 4 * w * h).tobytes() == want.tobytes()
+    for b in (src, dst):
+        b.free()
+
+
+def test_headless_cli_with_ranks_writes_the_same_image(device, tmp_path):
+    """rt_headless --ranks 1 (device group over RCCL, rows gathered to the first device) writes the image of the plain
+    single-device run, as PNG and PFM."""
+    import subprocess
+    exe = os.path.join(ROOT, "gpuraytracer_amd", "bin", "rt_headless")
+    common = [exe, "--synthetic", "4000", "--width", "96", "--height", "54", "--cycles", "2"]
+    a_png, a_pfm, b_png, b_pfm = (str(tmp_path / x) for x in ("a.png", "a.pfm", "b.png", "b.pfm"))
+    ra = subprocess.run(common + ["--out", a_png, "--pfm", a_pfm], capture_output=True, text=True, timeout=120)
+    rb = subprocess.run(common + ["--out", b_png, "--pfm", b_pfm, "--ranks", "1"], capture_output=True, text=True, timeout=120)
+    assert ra.returncode == 0, ra.stdout + ra.stderr
+    assert rb.returncode == 0, rb.stdout + rb.stderr
+    assert "Mrays/s" in rb.stdout
+    assert open(a_pfm, "rb").read() == open(b_pfm, "rb").read()
+    assert open(a_png, "rb").read() == open(b_png, "rb").read()
+
+
+# ------------------------------------------------------------------ dropping missed rays, merged vertices ----
+
+def _open_scene(n, seed=5):
+    """Random triangles without an enclosing box: most camera rays miss, and scattered rays leave the scene."""
+    from tests.test_gpu_parity import _small_scene
+    return _small_scene(n, seed=seed)
+
+
+@pytest.mark.parametrize("kernel,use_bvh,sort_rays", [(KERNEL_SPATIAL, True, 1), (KERNEL_QUAD, True, 1), (KERNEL_WAVE, True, 1),
+                                                        (KERNEL_SIMPLE, True, 1), (KERNEL_SPATIAL, False, 1), (KERNEL_SPATIAL, True, 0)])
+def test_dropping_missed_rays_changes_no_buffer(device, oracle, kernel, use_bvh, sort_rays):
+    """rt_device_set_drop_missed_rays: rays that missed are left out of the later bounces of their sample cycle instead
+    of being traced again (the reference's behaviour, shader/CS_TraceRays.hlsl:248,290-291). A ray that missed would
+    miss again, so every buffer equals the oracle's, which re-traces them - with fewer rays walked."""
+    from gpuraytracer_amd import capi
+    sc = _open_scene(700)
+    w, h, cycles, depth = 96, 54, 3, 4
+    op = oracle.Pipeline(sc, w, h, depth=depth, use_bvh=use_bvh, seed_raygen=1, seed_trace=2)
+    op.render(cycles * depth)
+    want = dict(output=op.output(), result=op.result(), emitted=op.emitted(), rays=op.rays().view(np.float32).reshape(-1, 8))
+    total = op.stats()[1]
+    op.close()
+    assert 0 < total["rays_hit"] < total["rays"] // 2, "the scene must let most rays miss"
+    tuning = capi.TraceTuning()
+    device.lib.rt_device_get_trace_tuning(device.handle, C.byref(tuning))
+    tuning.sort_rays = sort_rays
+    counted = {}
+    for drop in (0, 1):
+        stats = device.alloc(32)
+        capi.check(device.lib.rt_device_set_drop_missed_rays(device.handle, drop), "rt_device_set_drop_missed_rays")
+        if kernel in (KERNEL_WAVE, KERNEL_SIMPLE) or not use_bvh:
+            device.lib.rt_device_set_trace_stats(device.handle, stats.handle)
+        try:
+            g = _gpu_render(device, oracle, sc, w, h, cycles, depth, kernel=kernel, use_bvh=use_bvh, tuning=tuning, keep=ALL)
+        finally:
+            device.lib.rt_device_set_drop_missed_rays(device.handle, 0)
+            device.lib.rt_device_set_trace_stats(device.handle, None)
+        _same(g, want, "drop_missed_rays=%d, kernel %d" % (drop, kernel))
+        counted[drop] = int(stats.download(np.uint64, 4)[3])
+        stats.free()
+    if (kernel in (KERNEL_WAVE, KERNEL_SIMPLE) or not use_bvh) and (sort_rays or kernel == KERNEL_SIMPLE or not use_bvh):
+        print("rays walked: %d re-tracing misses, %d dropping them" % (counted[0], counted[1]))
+        assert counted[0] == total["rays"] and 0 < counted[1] < counted[0]
+
+
+def test_dropped_rays_come_back_with_new_camera_rays_and_new_scenes(device, oracle):
+    """The marks of missed rays end with the sample cycle (new camera rays) and with a rebuilt hierarchy: the moving
+    scene, rebuilt every cycle, in drop mode equals the oracle over several cycles."""
+    from gpuraytracer_amd import capi
+    sc = _open_scene(900, seed=8)
+    w, h, depth, cycles = 80, 45, 3, 3
+    capi.check(device.lib.rt_device_set_drop_missed_rays(device.handle, 1), "rt_device_set_drop_missed_rays")
+    try:
+        g = _gpu_render(device, oracle, sc, w, h, cycles, depth, keep=ALL, dynamic=True)
+    finally:
+        device.lib.rt_device_set_drop_missed_rays(device.handle, 0)
+    op = oracle.Pipeline(sc, w, h, depth=depth, seed_raygen=1, seed_trace=2, rebuild_every_cycle=True)
+    for frame in range(cycles):
+        op.set_vertices(oracle.synthetic_animate(sc, frame)["vertices"])
+        op.render(depth)
+    want = dict(output=op.output(), result=op.result(), emitted=op.emitted(), rays=op.rays().view(np.float32).reshape(-1, 8))
+    op.close()
+    _same(g, want, "moving open scene in drop mode")
+
+
+def test_merged_vertices_render_the_same_image(device, oracle, tmp_path):
+    """A mesh loaded with vertex de-duplication (shared vertices behind a real index buffer) renders the image of the
+    triangle soup the default loader makes: positions, normals, texture coordinates and materials per corner are equal."""
+    from gpuraytracer_amd import host_py
+    from tests.test_host_cpu import _write_shared_vertex_obj
+    obj = tmp_path / "box.obj"
+    _write_shared_vertex_obj(obj)
+    cam = dict(position=(0.2, 0.1, 0.3), focus=(1.0, 0.4, 0.0), up=(0.0, 1.0, 0.0), fov=1.2, near_z=0.01, far_z=100.0)
+    outs = []
+    for dedup in (False, True):
+        sc = host_py.load_scene(str(obj), camera=cam, dedup=dedup)
+        for use_accel in (True, False):
+            outs.append(_gpu_render(device, oracle, sc, 96, 54, 2, 3, use_accel=use_accel, keep=ALL))
+    assert len(sc["vertices"]) < len(sc["indices"])
+    for o in outs[1:]:
+        _same(o, outs[0], "merged vertices")
+    assert outs[0]["output"][..., :3].max() > 0.0

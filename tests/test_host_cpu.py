@@ -265,3 +265,76 @@ def test_image_writers_round_trip(tmp_path):
     assert raw.startswith(head)
     f = np.frombuffer(raw[len(head):], dtype="<f4").reshape(h, w, 3)[::-1]      # PFM rows run bottom to top
     assert f.tobytes() == np.ascontiguousarray(img[..., :3]).tobytes()
+
+
+def test_rows_dealt_to_ranks_cover_the_image_once():
+    """rt_rows_for_rank (host arithmetic only): rank r of N holds rows r, r + N, ...; together the ranks hold every row
+    once, ranks beyond the image hold none, and the Python twin used with torch.distributed agrees."""
+    import ctypes as C
+    from gpuraytracer_amd import capi
+    from gpuraytracer_amd.distributed import rows_for_rank
+    lib = capi.load()
+    for height in (0, 1, 2, 7, 8, 9, 1080, 2160, 4320):
+        for world in (1, 2, 3, 4, 8, 16):
+            seen = np.zeros(height, dtype=np.int32)
+            for rank in range(world):
+                r = capi.ImageRows()
+                assert lib.rt_rows_for_rank(height, world, rank, C.byref(r)) == capi.RT_OK
+                assert r.row_stride == world
+                assert (min(r.first_row, height), r.num_rows, r.row_stride) == tuple(min(x, height) if i == 0 else x for i, x in enumerate(rows_for_rank(height, world, rank)))
+                rows = r.first_row + r.row_stride * np.arange(r.num_rows)
+                assert np.all(rows < height)
+                seen[rows] += 1
+            assert np.all(seen == 1)
+    r = capi.ImageRows()
+    assert lib.rt_rows_for_rank(10, 0, 0, C.byref(r)) == capi.RT_ERR_INVALID_ARGUMENT
+    assert lib.rt_rows_for_rank(10, 4, 4, C.byref(r)) == capi.RT_ERR_INVALID_ARGUMENT
+    assert lib.rt_rows_for_rank(10, 4, 1, None) == capi.RT_ERR_INVALID_ARGUMENT
+
+
+def _write_shared_vertex_obj(path):
+    """A closed box of 12 triangles over 8 corners with per-face normals, one face listed twice, and a corner written once
+    as -0.0 and once as 0.0 (equal for the reference's float comparison)."""
+    corners = [(-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1), (-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1)]
+    faces = [((0, 1, 2, 3), (0, 0, -1)), ((4, 5, 6, 7), (0, 0, 1)), ((0, 1, 5, 4), (0, -1, 0)), ((2, 3, 7, 6), (0, 1, 0)),
+             ((1, 2, 6, 5), (1, 0, 0)), ((0, 3, 7, 4), (-1, 0, 0))]
+    (path.parent / "box.mtl").write_text("newmtl wall\nKd 0.8 0.7 0.6\nKe 0.4 0.5 0.6\nPr 0.5\n")
+    lines = ["mtllib box.mtl", "usemtl wall"] + ["v %g %g %g" % c for c in corners] + ["v -0.0 0 0", "v 0.0 0 0", "v 0 1 0"]
+    lines += ["vn %g %g %g" % n for _, n in faces] + ["vt 0 0", "vt 1 0", "vt 1 1", "vt 0 1"]
+    for k, (q, _) in enumerate(faces):
+        a, b, c, d = (i + 1 for i in q)
+        lines.append("f %d/1/%d %d/2/%d %d/3/%d" % (a, k + 1, b, k + 1, c, k + 1))
+        lines.append("f %d/1/%d %d/3/%d %d/4/%d" % (a, k + 1, c, k + 1, d, k + 1))
+    lines.append("f 1/1/1 2/2/1 3/3/1")                    # the first triangle once more
+    lines.append("f 9/1/1 11/2/1 10/1/1")                  # corners at -0 and +0 with equal attributes
+    path.write_text("\n".join(lines) + "\n")
+
+
+def test_vertex_deduplication_follows_the_switched_off_reference_loop(tmp_path):
+    """LoadMeshFromFile(bDeduplicate): every vertex gets the index of the first earlier unique vertex that the reference's
+    VerticesAreEqual accepts (position, UV, normal, material; src/RaytracerMesh.cpp:157-169, 249-275 of the reference) -
+    compared with that quadratic loop restated in numpy. The default stays Indices[i] == i."""
+    from gpuraytracer_amd import host_py
+    obj = tmp_path / "box.obj"
+    _write_shared_vertex_obj(obj)
+    plain = host_py.load_scene(str(obj))
+    dedup = host_py.load_scene(str(obj), dedup=True)
+    v = plain["vertices"]
+    assert np.array_equal(plain["indices"], np.arange(len(v), dtype=np.uint32))
+    want_idx, uniq = [], []
+    for i in range(len(v)):
+        for j, u in enumerate(uniq):
+            if (np.all(v["position"][i] == v["position"][u]) and np.all(v["uv"][i] == v["uv"][u]) and
+                    np.all(v["normal"][i] == v["normal"][u]) and v["material_id"][i] == v["material_id"][u]):
+                want_idx.append(j)
+                break
+        else:
+            want_idx.append(len(uniq))
+            uniq.append(i)
+    assert np.array_equal(dedup["indices"], np.array(want_idx, dtype=np.uint32))
+    assert len(dedup["vertices"]) == len(uniq) < len(v)
+    for field in ("position", "uv", "normal", "material_id"):
+        assert np.array_equal(dedup["vertices"][field], v[field][uniq])
+        assert np.array_equal(dedup["vertices"][field][dedup["indices"]], v[field])       # same triangles
+    assert dedup["indices"][-3] == dedup["indices"][-1] != dedup["indices"][-2]     # -0.0 and 0.0 are one vertex
+    assert np.array_equal(dedup["scene_min"], plain["scene_min"]) and np.array_equal(dedup["scene_max"], plain["scene_max"])
