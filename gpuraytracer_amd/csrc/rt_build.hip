@@ -222,7 +222,8 @@ __global__ __launch_bounds__(256) void k_morton_packed(SceneBounds sb, const flo
 __device__ __forceinline__ uint32_t axis_step(float c, float mn, float mx) {
     return (uint32_t)(saturatef((c - mn) / (mx - mn)) * (float)(RT_AXIS_STEPS - 1u));
 }
-__global__ __launch_bounds__(256) void k_axis_hist(SceneBounds sb, const float* __restrict__ dbounds, uint32_t n,
+// (a sample of the triangles is enough for steps of equal population: every `stride`-th triangle is counted)
+__global__ __launch_bounds__(256) void k_axis_hist(SceneBounds sb, const float* __restrict__ dbounds, uint32_t n, uint32_t stride,
                                                    const float4* __restrict__ tris, uint32_t* __restrict__ cells) {
     __shared__ uint32_t s_hist[3u * RT_AXIS_STEPS];
     for (uint32_t i = threadIdx.x; i < 3u * RT_AXIS_STEPS; i += 256u) s_hist[i] = 0u;
@@ -231,7 +232,9 @@ __global__ __launch_bounds__(256) void k_axis_hist(SceneBounds sb, const float* 
         sb.mn[0] = dbounds[0]; sb.mn[1] = dbounds[1]; sb.mn[2] = dbounds[2];
         sb.mx[0] = dbounds[4]; sb.mx[1] = dbounds[5]; sb.mx[2] = dbounds[6];
     }
-    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+    const uint32_t samples = (n + stride - 1u) / stride;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < samples; i += gridDim.x * 256u) {
+        const uint32_t t = i * stride;
         const float4 a = tris[3u * t], b = tris[3u * t + 1u], c = tris[3u * t + 2u];
         const float cx = 0.333333f * ((a.x + b.x) + c.x), cy = 0.333333f * ((a.y + b.y) + c.y), cz = 0.333333f * ((a.z + b.z) + c.z);
         atomicAdd(&s_hist[axis_step(cx, sb.mn[0], sb.mx[0])], 1u);
@@ -272,25 +275,12 @@ __device__ __forceinline__ uint32_t spread_bits3(uint32_t v) {
     v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
-__global__ __launch_bounds__(256) void k_spatial_keys(SceneBounds sb, const float* __restrict__ dbounds, uint32_t n,
-                                                      const uint2* __restrict__ sorted, const float4* __restrict__ tris,
-                                                      const uint32_t* __restrict__ cells, uint2* __restrict__ keys,
-                                                      uint32_t* __restrict__ ranks) {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= n) return;
-    if (dbounds) {
-        sb.mn[0] = dbounds[0]; sb.mn[1] = dbounds[1]; sb.mn[2] = dbounds[2];
-        sb.mx[0] = dbounds[4]; sb.mx[1] = dbounds[5]; sb.mx[2] = dbounds[6];
-    }
-    const uint32_t ci = sorted[r].y;
-    const float4 a = tris[ci], b = tris[ci + 1], c = tris[ci + 2];
-    const float cx = 0.333333f * ((a.x + b.x) + c.x), cy = 0.333333f * ((a.y + b.y) + c.y), cz = 0.333333f * ((a.z + b.z) + c.z);
-    const uint32_t* map = cells + RT_CELLS_AXIS;
+// key of the library's own hierarchy for a triangle with centroid (cx, cy, cz); map: k_axis_map's three tables
+__device__ __forceinline__ uint32_t spatial_key(float cx, float cy, float cz, const SceneBounds& sb, const uint32_t* __restrict__ map) {
     const uint32_t qx = map[axis_step(cx, sb.mn[0], sb.mx[0])];
     const uint32_t qy = map[RT_AXIS_STEPS + axis_step(cy, sb.mn[1], sb.mx[1])];
     const uint32_t qz = map[2u * RT_AXIS_STEPS + axis_step(cz, sb.mn[2], sb.mx[2])];
-    keys[r] = make_uint2((spread_bits3(qz) << 2) | (spread_bits3(qy) << 1) | spread_bits3(qx), ci);
-    ranks[ci / 3u] = r;
+    return (spread_bits3(qz) << 2) | (spread_bits3(qy) << 1) | spread_bits3(qx);
 }
 
 // ---- leaf slots of the library's own hierarchy by Morton cell ----
@@ -746,22 +736,22 @@ __device__ __forceinline__ void upsweep_block(Box mine, uint32_t k0, const rt_le
             l1 = has2 ? l0 + 1u : 0xffffffffu;
             store_node(nodes, lv.off[k] + gi, mine, l0, l1);
         }
-        if (pairs && k + 1u < lv.count) {              // same for the whole grid; the trunk is in nobody's record
+        if ((pairs || quads) && k + 1u < lv.count) {   // same for the whole grid; the trunk is in nobody's record
             if (cnt >= 2u) {
                 const Box other = next_lane_box(mine, gi + 1u < lv.n[k]);
                 const uint32_t o0 = __shfl_down(l0, 1, 64), o1 = __shfl_down(l1, 1, 64);
                 if (have && !(gi & 1u)) {
-                    store_pair(pairs, lv.aoff[k] + gi, mine, other, l0, l1, o0, o1);
+                    if (pairs) store_pair(pairs, lv.aoff[k] + gi, mine, other, l0, l1, o0, o1);
                     if (quads && quad_level(lv, k)) store_quad_pair(quads, lv, k, gi >> 1, mine, other);
                 }
             } else if (have) {
                 const bool quad = quads && quad_level(lv, k);
-                store_pair_half(pairs, lv.aoff[k] + (gi & ~1u), gi & 1u, mine, l0, l1);
+                if (pairs) store_pair_half(pairs, lv.aoff[k] + (gi & ~1u), gi & 1u, mine, l0, l1);
                 if (quad) store_quad_pair_half(quads, lv, k, gi >> 1, gi & 1u, mine);
                 if (!(gi & 1u) && gi + 1u >= lv.n[k]) {        // an only child: mark the other half as missing
                     Box none;
                     for (int a = 0; a < 3; a++) none.mn[a] = none.mx[a] = __uint_as_float(0x7fc00000u);
-                    store_pair_half(pairs, lv.aoff[k] + gi, 1u, none, 0xffffffffu, 0xffffffffu);
+                    if (pairs) store_pair_half(pairs, lv.aoff[k] + gi, 1u, none, 0xffffffffu, 0xffffffffu);
                     if (quad) store_quad_pair_half(quads, lv, k, gi >> 1, 1u, none);
                 }
             }
@@ -778,9 +768,16 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
                                                 const float4* __restrict__ tris, float4* __restrict__ sorted_tris,
                                                 rt_aabb* __restrict__ nodes, rt_aabb* __restrict__ pairs, float4* __restrict__ quads,
                                                 const uint32_t* __restrict__ cells, uint32_t slots_log2,
-                                                const uint32_t* __restrict__ ranks, float sliver_pad) {
+                                                const float4* __restrict__ ref_leaves, float sliver_pad,
+                                                uint2* __restrict__ own_keys, SceneBounds sb, const float* __restrict__ dbounds,
+                                                const uint32_t* __restrict__ axis_map) {
+    // Two builds use the extras. The reference's hierarchy, when the library's own is to follow: own_keys receives, for
+    // the sorted entries 2g and 2g + 1, (key of the own hierarchy, place in the reference's order) - the corners are in
+    // registers here, so the second sort needs no pass of its own over the triangles. The library's own hierarchy:
+    // ref_leaves are the reference's leaf records, sorted[] holds (key, place in the reference's order), and a triangle's
+    // corners and index slot come from the record of its leaf there (place / 2), one 128-byte line per triangle.
     __shared__ float s_box[256][6];
-    // with ranks: the sixth 16 bytes of a leaf record hold the places of its two triangles in the reference's order
+    // with ref_leaves: the sixth 16 bytes of a leaf record hold the places of its two triangles in the reference's order
     __shared__ uint2 s_rank[PACKED ? 256 : 1];
     // the workgroup's 256 leaf records are handed over through LDS so that they leave as runs of whole lines
     // (a lane storing its own record writes 16 bytes to each of 64 different lines per instruction: half the rate)
@@ -812,29 +809,65 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
         }
         store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
     }
+    uint32_t place0 = 0u, place1 = 0xffffffffu;        // with ref_leaves: the triangles' places in the reference's order
     if (have) {
         constexpr int STRIDE = PACKED ? 2 : 4;
         ci0 = sorted[(size_t)r0 * STRIDE + 1];
         if (two) ci1 = sorted[(size_t)(r0 + 1u) * STRIDE + 1];
         float corner[6][3];
+        if (PACKED && ref_leaves) {
+            place0 = ci0; place1 = two ? ci1 : 0xffffffffu;
+            // one half of an interleaved record (leaf_triangle_record): corners into corner[K .. K + 2], index slot into CI
+#define RT_REF_TRIANGLE(PLACE, K, CI)                                                                                          \
+            {                                                                                                                  \
+                const float4* l = ref_leaves + RT_LEAF_STRIDE * (size_t)((PLACE) >> 1);                                          \
+                const float4 l0 = l[0], l1 = l[1], l2 = l[2], l3 = l[3], l4 = l[4];                                              \
+                const bool second = ((PLACE) & 1u) != 0u;                                                                        \
+                corner[K][0] = second ? l0.y : l0.x; corner[K][1] = second ? l0.w : l0.z; corner[K][2] = second ? l1.y : l1.x;   \
+                corner[K + 1][0] = second ? l1.w : l1.z; corner[K + 1][1] = second ? l2.y : l2.x; corner[K + 1][2] = second ? l2.w : l2.z; \
+                corner[K + 2][0] = second ? l3.y : l3.x; corner[K + 2][1] = second ? l3.w : l3.z; corner[K + 2][2] = second ? l4.y : l4.x; \
+                CI = __float_as_uint(second ? l4.w : l4.z);                                                                    \
+            }
+            RT_REF_TRIANGLE(place0, 0, ci0)
+            if (two) RT_REF_TRIANGLE(place1, 3, ci1)
+#undef RT_REF_TRIANGLE
+        }
+        if (!(PACKED && ref_leaves)) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            if (i >= 3 && !two) {                       // no second triangle: repeat the first
-                corner[i][0] = corner[i - 3][0]; corner[i][1] = corner[i - 3][1]; corner[i][2] = corner[i - 3][2];
-                continue;
+            for (int i = 0; i < 6; i++) {
+                if (i < 3 || two) {
+                    if (PACKED) {
+                        const float4 p = tris[((i < 3) ? ci0 : ci1) + (uint32_t)(i % 3)];
+                        corner[i][0] = p.x; corner[i][1] = p.y; corner[i][2] = p.z;
+                    } else {
+                        const float* p = verts[indices[((i < 3) ? ci0 : ci1) + (uint32_t)(i % 3)]].position;
+                        corner[i][0] = p[0]; corner[i][1] = p[1]; corner[i][2] = p[2];
+                    }
+                }
             }
-            const uint32_t ci = (i < 3) ? ci0 : ci1;
-            float px, py, pz;
-            if (PACKED) {
-                const float4 p = tris[ci + (uint32_t)(i % 3)];
-                px = p.x; py = p.y; pz = p.z;
-            } else {
-                const float* p = verts[indices[ci + (uint32_t)(i % 3)]].position;
-                px = p[0]; py = p[1]; pz = p[2];
+        }
+        if (!two) {                                     // no second triangle: repeat the first
+#pragma unroll
+            for (int i = 0; i < 3; i++) { corner[3 + i][0] = corner[i][0]; corner[3 + i][1] = corner[i][1]; corner[3 + i][2] = corner[i][2]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {                   // (the repeated corners change no minimum or maximum)
+            b.mn[0] = fminf(b.mn[0], corner[i][0]); b.mn[1] = fminf(b.mn[1], corner[i][1]); b.mn[2] = fminf(b.mn[2], corner[i][2]);
+            b.mx[0] = fmaxf(b.mx[0], corner[i][0]); b.mx[1] = fmaxf(b.mx[1], corner[i][1]); b.mx[2] = fmaxf(b.mx[2], corner[i][2]);
+        }
+        if (PACKED && own_keys) {
+            if (dbounds) {
+                sb.mn[0] = dbounds[0]; sb.mn[1] = dbounds[1]; sb.mn[2] = dbounds[2];
+                sb.mx[0] = dbounds[4]; sb.mx[1] = dbounds[5]; sb.mx[2] = dbounds[6];
             }
-            corner[i][0] = px; corner[i][1] = py; corner[i][2] = pz;
-            b.mn[0] = fminf(b.mn[0], px); b.mn[1] = fminf(b.mn[1], py); b.mn[2] = fminf(b.mn[2], pz);
-            b.mx[0] = fmaxf(b.mx[0], px); b.mx[1] = fmaxf(b.mx[1], py); b.mx[2] = fmaxf(b.mx[2], pz);
+            float cen[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int a = 0; a < 3; a++) cen[t][a] = 0.333333f * ((corner[3 * t][a] + corner[3 * t + 1][a]) + corner[3 * t + 2][a]);
+            const uint2 k0 = make_uint2(spatial_key(cen[0][0], cen[0][1], cen[0][2], sb, axis_map), r0);
+            if (two) *reinterpret_cast<uint4*>(own_keys + r0) = make_uint4(k0.x, k0.y, spatial_key(cen[1][0], cen[1][1], cen[1][2], sb, axis_map), r0 + 1u);
+            else own_keys[r0] = k0;
         }
         if (PACKED) leaf_triangle_record(s_tri + 5u * threadIdx.x, corner, ci0, ci1);
         if (cells) {
@@ -863,8 +896,8 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
     if (PACKED) {
         // (an empty slot - cell layout only - is marked: its record is never read, because no ray enters its box,
         // and is not written)
-        s_rank[threadIdx.x] = (ranks && have) ? make_uint2(ranks[ci0 / 3u], two ? ranks[ci1 / 3u] : 0xffffffffu)
-                                              : make_uint2((cells && !have) ? 0xffffffffu : 0u, 0u);
+        s_rank[threadIdx.x] = (ref_leaves && have) ? make_uint2(place0, place1)
+                                                   : make_uint2((cells && !have) ? 0xffffffffu : 0u, 0u);
         __syncthreads();
         const uint32_t first = blockIdx.x * 256u;
 #pragma unroll
@@ -878,11 +911,11 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
                                       : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         }
     }
-    if (PACKED && pairs) {                             // same for the whole grid
+    if (PACKED && (pairs || quads)) {                  // same for the whole grid
         const Box other = next_lane_box(b, g + 1u < leaves);
         const uint32_t o0 = __shfl_down(ci0, 1, 64), o1 = __shfl_down(ci1, 1, 64);
         if (g < leaves && !(g & 1u)) {
-            store_pair(pairs, lv.aoff[0] + g, b, other, ci0 | 0x80000000u, ci1 | 0x80000000u, o0 | 0x80000000u, o1 | 0x80000000u);
+            if (pairs) store_pair(pairs, lv.aoff[0] + g, b, other, ci0 | 0x80000000u, ci1 | 0x80000000u, o0 | 0x80000000u, o1 | 0x80000000u);
             if (quads && quad_level(lv, 0u)) store_quad_pair(quads, lv, 0u, g >> 1, b, other);
         }
     }
@@ -1027,6 +1060,21 @@ int rt_private_copy_from_reference(rt_device* dev, uint32_t num_prims, const rt_
     return rt_launch_status();
 }
 
+int rt_accel_pairs(rt_accel* a, bool own, const rt_aabb* nodes, const float4** pairs) {
+    bool& valid = own ? a->sp_pairs_valid : a->pairs_valid;
+    rt_aabb* out = own ? a->sp_pairs : a->pairs;
+    *pairs = (const float4*)out;
+    if (valid) return RT_OK;
+    rt_levels lv;
+    if (own) lv = a->sp_lv;
+    else if (!rt_make_levels(a->num_prims, &lv)) return RT_ERR_TOO_FEW_PRIMITIVES;
+    uint32_t total_pairs = 0u;
+    for (uint32_t k = 0; k + 1u < lv.count; k++) total_pairs += (lv.n[k] + 1u) / 2u;
+    hipLaunchKernelGGL(k_pairs_from_nodes, dim3(div_up(total_pairs, 256u)), dim3(256), 0, a->dev->stream, lv, total_pairs, nodes, out);
+    valid = true;
+    return rt_launch_status();
+}
+
 int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted) {
     int rc = rt_sort_workspace(dev, n);
     if (rc) return rc;
@@ -1144,7 +1192,8 @@ int rt_bvh_build_leaves(rt_device* dev, const rt_bvh_info* info, const rt_buffer
     hipLaunchKernelGGL((k_leaves<false, false>), dim3(div_up(leaves, 256u)), dim3(256), 0, dev->stream, n, lv,
                        (const uint32_t*)morton_codes->ptr, (const uint32_t*)indices->ptr, (const rt_vertex*)vertices->ptr,
                        (const float4*)nullptr, (float4*)nullptr, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, (float4*)nullptr,
-                       (const uint32_t*)nullptr, 0u, (const uint32_t*)nullptr, 0.0f);
+                       (const uint32_t*)nullptr, 0u, (const float4*)nullptr, 0.0f, (uint2*)nullptr, SceneBounds{}, (const float*)nullptr,
+                       (const uint32_t*)nullptr);
     return rt_launch_status();
 }
 
@@ -1177,7 +1226,8 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
     a->tris = a->sorted_tris = a->quads = a->sp_quads = a->sp_tris = nullptr;
     a->keys_a = a->keys_b = nullptr;
     a->pairs = a->sp_pairs = a->sp_nodes = nullptr;
-    a->ranks = a->cells = nullptr;
+    a->cells = nullptr;
+    a->pairs_valid = a->sp_pairs_valid = false;
     a->sp_built = false;
     a->want_spatial = true;
     a->cell_bits_cap = RT_CELL_BITS_MAX;
@@ -1205,7 +1255,6 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
         if (e == hipSuccess) e = hipMalloc((void**)&a->sp_nodes, (size_t)rt_bvh_node_count(2u * slots) * sizeof(rt_aabb));
         if (e == hipSuccess) e = hipMalloc((void**)&a->sp_tris, (size_t)slots * RT_LEAF_STRIDE * sizeof(float4));
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&a->ranks, (size_t)max_primitives * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&a->cells, (size_t)RT_CELLS_WORDS * sizeof(uint32_t));
     if (e != hipSuccess) {
         rt_accel_destroy(a);
@@ -1229,7 +1278,6 @@ int rt_accel_destroy(rt_accel* a) {
     if (a->sp_pairs) (void)hipFree(a->sp_pairs);
     if (a->sp_quads) (void)hipFree(a->sp_quads);
     if (a->sp_tris) (void)hipFree(a->sp_tris);
-    if (a->ranks) (void)hipFree(a->ranks);
     if (a->cells) (void)hipFree(a->cells);
     delete a;
     return RT_OK;
@@ -1366,29 +1414,36 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
 
     hipLaunchKernelGGL(k_morton_packed, dim3(div_up(n, 256u)), dim3(256), 0, s, make_bounds(scene_min, scene_max), dbounds, n,
                        a->tris, a->keys_a);
+    // The library's own hierarchy (rt_accel_set_second_hierarchy): same triangles, same kernels, keys without overlapping
+    // bits. Its keys' coordinates come from per-axis histograms of the centroids, which only need the triangles:
+    const bool own = a->want_spatial && a->sp_tris != nullptr;
+    const SceneBounds spb = make_bounds(scene_min, scene_max);
+    if (own) {
+        RT_HIP(hipMemsetAsync(a->cells + RT_CELLS_AXIS, 0, (size_t)3u * RT_AXIS_STEPS * sizeof(uint32_t), s));
+        const uint32_t stride = n > (1u << 20) ? (n >> 20) + 1u : 1u;         // about a million samples are plenty
+        const uint32_t samples = div_up(n, stride);
+        hipLaunchKernelGGL(k_axis_hist, dim3(min(div_up(samples, 256u), 512u)), dim3(256), 0, s, spb, dbounds, n, stride, a->tris, a->cells);
+        hipLaunchKernelGGL(k_axis_map, dim3(3), dim3(1024), 0, s, samples, a->cells);
+    }
     uint2* src = nullptr;
     rc = rt_sort_pairs(dev, a->keys_a, a->keys_b, n, 4u, &src);     // four passes: the sorted pairs are back in keys_a
     if (rc) return rc;
+    uint2* other = src == a->keys_a ? a->keys_b : a->keys_a;
     const uint32_t leaves = lv.n[0];
+    // the pair records are not written here: the traversal kernels that read them have them made on demand
+    a->pairs_valid = a->sp_pairs_valid = false;
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)src,
-                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, a->pairs,
-                       a->quads, (const uint32_t*)nullptr, 0u, (const uint32_t*)nullptr, 0.0f);
+                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr,
+                       a->quads, (const uint32_t*)nullptr, 0u, (const float4*)nullptr, 0.0f, own ? other : (uint2*)nullptr, spb, dbounds,
+                       (const uint32_t*)(a->cells + RT_CELLS_AXIS));
     for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
-        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, a->pairs, a->quads);
+        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, a->quads);
     if (morton_codes)
         hipLaunchKernelGGL(k_expand_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, n, src, (uint4*)morton_codes->ptr);
 
-    // the library's own hierarchy: same triangles, same kernels, keys without overlapping bits. Only the traversal
-    // kernel that walks it needs it (rt_accel_set_second_hierarchy).
-    a->sp_built = a->want_spatial && a->sp_tris != nullptr;
-    if (!a->sp_built) return rt_launch_status();
-    uint2* other = src == a->keys_a ? a->keys_b : a->keys_a;
-    const SceneBounds spb = make_bounds(scene_min, scene_max);
-    RT_HIP(hipMemsetAsync(a->cells + RT_CELLS_AXIS, 0, (size_t)3u * RT_AXIS_STEPS * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(k_axis_hist, dim3(min(div_up(n, 256u), 512u)), dim3(256), 0, s, spb, dbounds, n, a->tris, a->cells);
-    hipLaunchKernelGGL(k_axis_map, dim3(3), dim3(1024), 0, s, n, a->cells);
-    hipLaunchKernelGGL(k_spatial_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, spb, dbounds, n, src,
-                       a->tris, (const uint32_t*)a->cells, other, a->ranks);
+    a->sp_built = own;
+    if (!own) return rt_launch_status();
+    // (key, place in the reference's order) of every triangle, written by the leaf kernel above, sorted by key
     uint2* sp_src = nullptr;
     rc = rt_sort_pairs(dev, other, src, n, 4u, &sp_src);
     if (rc) return rc;
@@ -1404,10 +1459,11 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     hipLaunchKernelGGL(k_cell_choose, dim3(1), dim3(1024), 0, s, a->cells, slots_log2, a->cell_bits_cap);
     hipLaunchKernelGGL(k_cell_starts, dim3(div_up(n, 256u)), dim3(256), 0, s, n, (const uint2*)sp_src, a->cells);
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(slots, 256u)), dim3(256), 0, s, 2u * slots, sl, (const uint32_t*)sp_src,
-                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, a->sp_pairs, a->sp_quads,
-                       (const uint32_t*)a->cells, slots_log2, (const uint32_t*)a->ranks, dev->walk_sliver_pad);
+                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads,
+                       (const uint32_t*)a->cells, slots_log2, (const float4*)a->sorted_tris, dev->walk_sliver_pad, (uint2*)nullptr, spb,
+                       (const float*)nullptr, (const uint32_t*)nullptr);
     for (uint32_t k0 = 8u; k0 + 1u < sl.count; k0 += 8u)
-        hipLaunchKernelGGL(k_upsweep, dim3(div_up(sl.n[k0], 256u)), dim3(256), 0, s, k0, sl, a->sp_nodes, a->sp_pairs, a->sp_quads);
+        hipLaunchKernelGGL(k_upsweep, dim3(div_up(sl.n[k0], 256u)), dim3(256), 0, s, k0, sl, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads);
     return rt_launch_status();
 }
 

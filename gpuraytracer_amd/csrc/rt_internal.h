@@ -121,6 +121,9 @@ int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passe
 // Writes the private copy (interleaved sibling pairs, Morton-ordered packed triangles: see rt_levels and
 // rt_accel) of a hierarchy held in the reference's layout. pairs: rt_aligned_node_slots() slots;
 // sorted_tris: 5 float4 per leaf.
+// The sibling-pair records of an accel's hierarchy (own = the library's own one), made from its nodes on first use after
+// a build: only the one-level kernel, the counting variants and the ray-order probe read them.
+int rt_accel_pairs(rt_accel* accel, bool own, const rt_aabb* nodes, const float4** pairs);
 int rt_private_copy_from_reference(rt_device* dev, uint32_t num_prims, const rt_aabb* nodes, const uint32_t* indices,
                                    const rt_vertex* verts, rt_aabb* pairs, float4* sorted_tris, float4* quads);
 
@@ -196,12 +199,12 @@ struct rt_accel {
     uint2* keys_b;             // [max_prims]
     // The library's own hierarchy over the same triangles (same kernels, same shape, codes whose bits do not
     // overlap), for the traversal that does not follow the reference's order: nodes, sibling pairs, records of
-    // four grandchildren, leaves; and every triangle's place in the reference's order.
+    // four grandchildren, leaves (whose records also hold their triangles' places in the reference's order).
     rt_aabb* sp_nodes;
     rt_aabb* sp_pairs;
     float4* sp_quads;
     float4* sp_tris;
-    uint32_t* ranks;           // [max_prims]
+    bool pairs_valid, sp_pairs_valid;      // pairs / sp_pairs hold the records of the last build (made on demand, see rt_accel_pairs)
     uint32_t* cells;           // Morton-cell bookkeeping of the last build: see the offsets below
     bool want_spatial;         // rt_accel_set_second_hierarchy: builds make the library's own hierarchy
     uint32_t cell_bits_cap;    // ... with leaf slots aligned to Morton cells of at most this many bits

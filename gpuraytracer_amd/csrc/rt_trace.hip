@@ -800,10 +800,11 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
                             bool walk = slab(org, inv_d, tmin_r, tmax_r, root_lo, root_hi) != 1e30f;
                             h = 1u; trail = 0ull;
                             if (walk && odd_first) {
-                                float bt0, bt1;
-                                slab_pair(org, inv_d, tmin_r, tmax_r, pairs[4], pairs[5], pairs[6], bt0, bt1);
+                                // the trunk's two children, exact boxes, from the nodes in the reference's layout
+                                const float4* c = nodes + 2 * (size_t)p.lv.off[root_level - 1u];
+                                const float bt0 = slab(org, inv_d, tmin_r, tmax_r, c[0], c[1]), bt1 = slab(org, inv_d, tmin_r, tmax_r, c[2], c[3]);
                                 const bool hit0 = (bt0 != 1e30f) && (bt0 < best.t);
-                                const bool hit1 = (bt1 != 1e30f) && (bt1 < best.t);      // a missing child is NaNs: no hit
+                                const bool hit1 = (bt1 != 1e30f) && (bt1 < best.t);
                                 walk = hit0 || hit1;
                                 h = hit0 ? 2u : 3u;
                                 trail = (hit0 && hit1) ? 8ull : 0ull;
@@ -949,7 +950,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                                                        const float4* __restrict__ sorted_tris, float4* __restrict__ hit_records,
                                                        uint32_t* __restrict__ hit_ci, uint32_t* __restrict__ queue,
                                                        const uint2* __restrict__ order, const float4* __restrict__ ref_tris,
-                                                       const uint32_t* __restrict__ ranks, uint2* __restrict__ flagged,
+                                                       uint2* __restrict__ flagged,
                                                        uint32_t* __restrict__ flag_count, unsigned long long* __restrict__ walk_stats,
                                                        const uint32_t* __restrict__ live) {
     extern __shared__ uint32_t s_dyn[];
@@ -1034,10 +1035,11 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                         // the trunk is entered on any box hit
                         keep = slab(c_org, c_inv, c_tmin, c_tmax, root_lo, root_hi) != 1e30f;
                         if (keep && odd_first) {
-                            float bt0, bt1;
-                            slab_pair(c_org, c_inv, c_tmin, c_tmax, pairs[4], pairs[5], pairs[6], bt0, bt1);
+                            // the trunk's two children, exact boxes, from the nodes in the reference's layout
+                            const float4* c = nodes + 2 * (size_t)p.lv.off[root_level - 1u];
+                            const float bt0 = slab(c_org, c_inv, c_tmin, c_tmax, c[0], c[1]), bt1 = slab(c_org, c_inv, c_tmin, c_tmax, c[2], c[3]);
                             const bool hit0 = (bt0 != 1e30f) && (bt0 < c_tmax);
-                            const bool hit1 = (bt1 != 1e30f) && (bt1 < c_tmax);      // a missing child is NaNs: no hit
+                            const bool hit1 = (bt1 != 1e30f) && (bt1 < c_tmax);
                             keep = hit0 || hit1;
                             c_h = hit0 ? 2u : 3u;
                             c_trail = (hit0 && hit1) ? 8u : 0u;
@@ -1493,9 +1495,16 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     const float4* quads = nullptr;
     const float4* key_nodes = nodes;      // the hierarchy the walk-length estimate is taken on
     const float4* key_pairs = nullptr;
+    // (sibling-pair records: read by the one-level walk - also the counting variant and the fallback for what the
+    // two-level kernels cannot address - and by the ray-order probe; an accel has them made on first use after a build)
+    const bool offsets_fit = rt_aligned_node_slots(&p.lv) * sizeof(rt_aabb) <= 0xffffffffull && (size_t)p.lv.n[0] * 128u <= 0xffffffffull;
+    const bool one_level_walk = stats || divide || !((spatial_kernel || quad_kernel) && offsets_fit && p.lv.count >= 3u);
     if (accel) {
-        pairs = (const float4*)accel->pairs;
         quads = (const float4*)accel->quads;
+        if (one_level_walk) {
+            rc = rt_accel_pairs(const_cast<rt_accel*>(accel), false, (const rt_aabb*)bvh->ptr, &pairs);
+            if (rc) return rc;
+        }
     } else {
         rc = convert_workspace(dev, p.num_prims, p.lv);
         if (rc) return rc;
@@ -1527,7 +1536,12 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         uint32_t cost_shift = 0u;
         while (((nodes_there / probe_stride) >> cost_shift) > (1u << cost_bits) - 1u) cost_shift++;
         key_nodes = on_spatial ? (const float4*)accel->sp_nodes : nodes;
-        key_pairs = on_spatial ? (const float4*)accel->sp_pairs : pairs;
+        key_pairs = pairs;
+        if (nodes_there && accel) {          // the probe reads pair records
+            rc = rt_accel_pairs(const_cast<rt_accel*>(accel), on_spatial, on_spatial ? accel->sp_nodes : (const rt_aabb*)bvh->ptr, &key_pairs);
+            if (rc) return rc;
+            if (!on_spatial) pairs = key_pairs;
+        }
         hipLaunchKernelGGL(k_ray_keys, grid, block, 0, s, nr, ray_in, key_nodes, key_pairs, 1u << (depth - 1u), (nodes_there + 1u) / 2u,
                            probe_stride, cost_shift, key_passes == 1u ? 8u : cost_bits, 8u * key_passes, dev->ray_keys_a,
                            (const uint8_t*)(live ? missed : nullptr), live);
@@ -1554,8 +1568,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         timing = dev->timing_events + 2u * dev->timing_count;
         RT_HIP(hipEventRecord(timing[0], s));
     }
-    // k_traverse_quad addresses its records and the leaves with 32-bit byte offsets
-    const bool offsets_fit = rt_aligned_node_slots(&p.lv) * sizeof(rt_aabb) <= 0xffffffffull && (size_t)p.lv.n[0] * 128u <= 0xffffffffull;
+    // (k_traverse_quad addresses its records and the leaves with 32-bit byte offsets: offsets_fit)
     if (stats && divide) RT_LAUNCH_TRAVERSE(true, true);
     else if (stats) RT_LAUNCH_TRAVERSE(true, false);
     else if (divide) RT_LAUNCH_TRAVERSE(false, true);
@@ -1570,7 +1583,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
                        (size_t)(kFifo * 512u + 4u * kStockFields * 64u) * sizeof(uint32_t), s, ps, ray_in,                      \
                        (const float4*)accel->sp_nodes, (const float4*)accel->sp_pairs, (const float4*)accel->sp_quads,          \
                        (const float4*)accel->sp_tris, dev->hit_records, dev->hit_ci, dev->queue_counter, order, st,            \
-                       (const uint32_t*)accel->ranks, dev->listed_rays, listed, dev->walk_stats, (const uint32_t*)live)
+                       dev->listed_rays, listed, dev->walk_stats, (const uint32_t*)live)
         if (dev->walk_stats) RT_LAUNCH_SPATIAL(true);
         else RT_LAUNCH_SPATIAL(false);
 #undef RT_LAUNCH_SPATIAL
