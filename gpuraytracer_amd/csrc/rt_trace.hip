@@ -52,6 +52,7 @@ struct TraceParams {
     uint32_t refill_threshold; // lanes that must be free before a wave of k_traverse_quad takes new rays
     uint32_t deal_shift;       // blocks of 2^deal_shift consecutive positions of the ray order are dealt to the queues in turn
     float beyond;              // k_traverse_spatial enters boxes up to reach * beyond
+    uint32_t trunk_children;   // node index (reference layout) of the first of the trunk's two children, for hierarchy lv
     rt_levels lv;
 };
 
@@ -464,12 +465,13 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
                                                   unsigned long long* __restrict__ stats, const uint32_t* __restrict__ live) {
     extern __shared__ uint32_t s_dyn[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t num_rays = p.num_rays, queue_chunk = p.queue_chunk;      // (the kernel argument itself stays untouched: in registers)
     if (live) {
         // drop-missed-rays mode: the rays to walk are the first *live entries of order (k_ray_keys put the others last)
-        p.num_rays = *live;
-        if (p.num_rays == 0u) return;
+        num_rays = *live;
+        if (num_rays == 0u) return;
         const uint32_t deal_block = 1u << p.deal_shift;
-        p.queue_chunk = ((((p.num_rays + deal_block - 1u) >> p.deal_shift) + 7u) / 8u) * deal_block;
+        queue_chunk = ((((num_rays + deal_block - 1u) >> p.deal_shift) + 7u) / 8u) * deal_block;
     }
     const uint32_t root_level = p.lv.count - 1u;
     const uint32_t first_leaf = 1u << root_level;              // slot of leaf 0
@@ -503,8 +505,8 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
             if (queues_tried >= 8u) {
                 exhausted = exhausted || need;             // every queue has been seen empty
             } else {
-                const uint32_t q_begin = q * p.queue_chunk;
-                const uint32_t q_end = q_begin + p.queue_chunk;
+                const uint32_t q_begin = q * queue_chunk;
+                const uint32_t q_end = q_begin + queue_chunk;
                 const uint32_t leader = (uint32_t)__builtin_ctzll(need_mask);
                 uint32_t base = 0u;
                 if (lane == leader) base = atomicAdd(queue + 8u * q, (uint32_t)__popcll(need_mask));
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(256) void k_traverse(TraceParams p, const float4* _
                         // queues in turn, so that every queue starts with long walks) -> ray
                         const uint32_t slot = mine - q_begin;
                         const uint32_t pos = (((slot >> p.deal_shift) * 8u + q) << p.deal_shift) | (slot & ((1u << p.deal_shift) - 1u));
-                        if (pos < p.num_rays) {                // the last block may be short: such a lane asks again
+                        if (pos < num_rays) {                  // the last block may be short: such a lane asks again
                         const uint32_t rid = order ? order[pos].y : pos;
                         const float4 r0 = rays[2 * (size_t)rid], r1 = rays[2 * (size_t)rid + 1];
                         org = mk(r0.x, r0.y, r0.z); dir = mk(r0.w, r1.x, r1.y);
@@ -730,12 +732,13 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
                                                        const uint2* __restrict__ order, const uint32_t* __restrict__ listed) {
     extern __shared__ uint32_t s_dyn[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t num_rays = p.num_rays, queue_chunk = p.queue_chunk;      // (the kernel argument itself stays untouched: in registers)
     if (listed) {
         // the rays are the first *listed entries of order: a list another kernel of the same stream has filled
-        p.num_rays = *listed;
-        if (p.num_rays == 0u) return;
+        num_rays = *listed;
+        if (num_rays == 0u) return;
         const uint32_t deal_block = 1u << p.deal_shift;
-        p.queue_chunk = ((((p.num_rays + deal_block - 1u) >> p.deal_shift) + 7u) / 8u) * deal_block;
+        queue_chunk = ((((num_rays + deal_block - 1u) >> p.deal_shift) + 7u) / 8u) * deal_block;
     }
     const uint32_t root_level = p.lv.count - 1u;               // >= 2
     const uint32_t first_leaf = 1u << root_level;              // slot of leaf 0
@@ -769,8 +772,8 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
             if (queues_tried >= 8u) {
                 if (w == kIdle) w = kDry;
             } else {
-                const uint32_t q_begin = q * p.queue_chunk;
-                const uint32_t q_end = q_begin + p.queue_chunk;
+                const uint32_t q_begin = q * queue_chunk;
+                const uint32_t q_end = q_begin + queue_chunk;
                 const uint32_t leader = (uint32_t)__builtin_ctzll(need_mask);
                 uint32_t base = 0u;
                 if (lane == leader) base = atomicAdd(queue + 8u * q, (uint32_t)__popcll(need_mask));
@@ -784,7 +787,7 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
                     if (mine < q_end) {
                         const uint32_t slot = mine - q_begin;
                         const uint32_t pos = (((slot >> p.deal_shift) * 8u + q) << p.deal_shift) | (slot & ((1u << p.deal_shift) - 1u));
-                        if (pos < p.num_rays) {
+                        if (pos < num_rays) {
                             const uint32_t rid = order ? order[pos].y : pos;
                             const float4 r0 = rays[2 * (size_t)rid], r1 = rays[2 * (size_t)rid + 1];
                             org = mk(r0.x, r0.y, r0.z); dir = mk(r0.w, r1.x, r1.y);
@@ -801,7 +804,7 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
                             h = 1u; trail = 0ull;
                             if (walk && odd_first) {
                                 // the trunk's two children, exact boxes, from the nodes in the reference's layout
-                                const float4* c = nodes + 2 * (size_t)p.lv.off[root_level - 1u];
+                                const float4* c = nodes + 2 * (size_t)p.trunk_children;
                                 const float bt0 = slab(org, inv_d, tmin_r, tmax_r, c[0], c[1]), bt1 = slab(org, inv_d, tmin_r, tmax_r, c[2], c[3]);
                                 const bool hit0 = (bt0 != 1e30f) && (bt0 < best.t);
                                 const bool hit1 = (bt1 != 1e30f) && (bt1 < best.t);
@@ -955,12 +958,13 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                                                        const uint32_t* __restrict__ live) {
     extern __shared__ uint32_t s_dyn[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    uint32_t num_rays = p.num_rays, queue_chunk = p.queue_chunk;      // (the kernel argument itself stays untouched: in registers)
     if (live) {
         // drop-missed-rays mode: the rays to walk are the first *live entries of order (k_ray_keys put the others last)
-        p.num_rays = *live;
-        if (p.num_rays == 0u) return;
+        num_rays = *live;
+        if (num_rays == 0u) return;
         const uint32_t deal_block = 1u << p.deal_shift;
-        p.queue_chunk = ((((p.num_rays + deal_block - 1u) >> p.deal_shift) + 7u) / 8u) * deal_block;
+        queue_chunk = ((((num_rays + deal_block - 1u) >> p.deal_shift) + 7u) / 8u) * deal_block;
     }
     const uint32_t root_level = p.lv.count - 1u;               // >= 2
     const uint32_t first_leaf = 1u << root_level;              // slot of leaf 0
@@ -1008,8 +1012,8 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
         const unsigned long long need_mask = __builtin_amdgcn_ballot_w64(w == kIdle);
         if (need_mask && ((uint32_t)__popcll(need_mask) >= p.refill_threshold || !__builtin_amdgcn_ballot_w64(w <= kFifo - 1u))) {
             while (stock_next == stock_count && queues_tried < 8u) {             // wave-uniform
-                const uint32_t q_begin = q * p.queue_chunk;
-                const uint32_t q_end = q_begin + p.queue_chunk;
+                const uint32_t q_begin = q * queue_chunk;
+                const uint32_t q_end = q_begin + queue_chunk;
                 uint32_t base = 0u;
                 if (lane == 0u) base = atomicAdd(queue + 8u * q, 64u);
                 base = q_begin + (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -1026,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                 if (mine < q_end) {
                     const uint32_t slot = mine - q_begin;
                     const uint32_t pos = (((slot >> p.deal_shift) * 8u + q) << p.deal_shift) | (slot & ((1u << p.deal_shift) - 1u));
-                    if (pos < p.num_rays) {
+                    if (pos < num_rays) {
                         c_rid = order ? order[pos].y : pos;
                         const float4 r0 = rays[2 * (size_t)c_rid], r1 = rays[2 * (size_t)c_rid + 1];
                         c_org = mk(r0.x, r0.y, r0.z); c_dir = mk(r0.w, r1.x, r1.y);
@@ -1036,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                         keep = slab(c_org, c_inv, c_tmin, c_tmax, root_lo, root_hi) != 1e30f;
                         if (keep && odd_first) {
                             // the trunk's two children, exact boxes, from the nodes in the reference's layout
-                            const float4* c = nodes + 2 * (size_t)p.lv.off[root_level - 1u];
+                            const float4* c = nodes + 2 * (size_t)p.trunk_children;
                             const float bt0 = slab(c_org, c_inv, c_tmin, c_tmax, c[0], c[1]), bt1 = slab(c_org, c_inv, c_tmin, c_tmax, c[2], c[3]);
                             const bool hit0 = (bt0 != 1e30f) && (bt0 < c_tmax);
                             const bool hit1 = (bt1 != 1e30f) && (bt1 < c_tmax);
@@ -1433,6 +1437,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         if (bvh->bytes < (size_t)rt_bvh_node_count(p.num_prims) * 32u) return RT_ERR_BUFFER_TOO_SMALL;
         if (accel && accel->num_prims != p.num_prims) return RT_ERR_INVALID_ARGUMENT;
     }
+    p.trunk_children = p.lv.count >= 2u ? p.lv.off[p.lv.count - 2u] : 0u;
     ShadeBuffers b;
     b.indices = (const uint32_t*)indices->ptr;
     b.verts = (const rt_vertex*)vertices->ptr;
@@ -1578,6 +1583,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         dev->listed_valid = true;
         TraceParams ps = p;
         ps.lv = accel->sp_lv;
+        ps.trunk_children = ps.lv.count >= 2u ? ps.lv.off[ps.lv.count - 2u] : 0u;
 #define RT_LAUNCH_SPATIAL(COUNT)                                                                                              \
     hipLaunchKernelGGL((k_traverse_spatial<COUNT>), dim3(groups), block,                                                      \
                        (size_t)(kFifo * 512u + 4u * kStockFields * 64u) * sizeof(uint32_t), s, ps, ray_in,                      \

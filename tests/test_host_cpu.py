@@ -338,3 +338,31 @@ def test_vertex_deduplication_follows_the_switched_off_reference_loop(tmp_path):
         assert np.array_equal(dedup["vertices"][field][dedup["indices"]], v[field])       # same triangles
     assert dedup["indices"][-3] == dedup["indices"][-1] != dedup["indices"][-2]     # -0.0 and 0.0 are one vertex
     assert np.array_equal(dedup["scene_min"], plain["scene_min"]) and np.array_equal(dedup["scene_max"], plain["scene_max"])
+
+
+def test_no_kernel_uses_scratch():
+    """The compiler's resource remarks saved by the build (gpuraytracer_amd/lib/*.resources.txt): no kernel of the library
+    keeps data in scratch memory, and the default traversal kernel still fits four waves per SIMD. A kernel argument
+    that is written to, or a dynamically indexed local array, silently moves to scratch and costs the walk 15 %."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "gpuraytracer_amd", "lib", "*.resources.txt")))
+    if not files:
+        pytest.skip("the library was built without resource remarks")
+    kernels = {}
+    for path in files:
+        name = None
+        for line in open(path):
+            m = re.search(r"remark: Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                kernels[name] = {}
+                continue
+            m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|VGPRs|Occupancy \[waves/SIMD\]|VGPRs Spill|SGPRs Spill): (\d+)", line)
+            if m and name:
+                kernels[name][m.group(1)] = int(m.group(2))
+    assert len(kernels) >= 30
+    for name, r in kernels.items():
+        assert r.get("ScratchSize [bytes/lane]", 0) == 0 and r.get("VGPRs Spill", 0) == 0, "%s uses scratch: %s" % (name, r)
+    walk = [r for n, r in kernels.items() if "k_traverse_spatialILb0" in n]
+    assert len(walk) == 1 and walk[0]["Occupancy [waves/SIMD]"] >= 4
