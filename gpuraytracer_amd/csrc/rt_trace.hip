@@ -1003,6 +1003,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
     uint32_t wait_head = 0u;
     uint32_t q = blockIdx.x & 7u, queues_tried = 0u;       // wave-uniform
     uint32_t n_steps = 0u, n_empty = 0u, n_leaves = 0u;    // COUNT: this wave's steps, steps that hit nothing, leaves tested
+    uint32_t n_turns = 0u, n_rounds = 0u;                  // COUNT: turns of the walking loop and triangle rounds of this wave
 
     for (;;) {
         // 1. Lanes without a ray take one from the wave's stock in LDS. The stock is filled 64 rays at a time by the
@@ -1099,6 +1100,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                     atomicAdd(walk_stats, (unsigned long long)n_steps);
                     atomicAdd(walk_stats + 1, (unsigned long long)n_empty);
                     atomicAdd(walk_stats + 2, (unsigned long long)n_leaves);
+                    atomicAdd(walk_stats + 3, (unsigned long long)n_turns | ((unsigned long long)n_rounds << 40));
                 }
                 break;
             }
@@ -1108,6 +1110,8 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
         // 2. walk until a triangle round is due, a lane has finished its ray, or nobody can walk
         unsigned long long waiting_mask, walking_mask;
         for (;;) {
+            bool empty_step = false;                       // COUNT: this lane's step found none of the four boxes hit
+            if (COUNT) { n_turns += 1u; n_steps += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(w <= kFifo - 1u)); }
             if (w <= kFifo - 1u) {
                 const uint4* rec = reinterpret_cast<const uint4*>(quad_bytes + (h << 6));
                 const uint4 u0 = rec[0], u1 = rec[1], u2 = rec[2];
@@ -1129,10 +1133,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                 const bool hit2 = !(tx2 < vmax(tn2, lim)) && (tn2 <= reach_in);
                 const bool hit3 = !(tx3 < vmax(tn3, lim)) && (tn3 <= reach_in);
                 const uint32_t m = (hit0 ? 1u : 0u) | (hit1 ? 2u : 0u) | (hit2 ? 4u : 0u) | (hit3 ? 8u : 0u);
-                if (COUNT) {
-                    n_steps += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(true));
-                    n_empty += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(m == 0u));
-                }
+                if (COUNT) empty_step = m == 0u;
                 if (h < first_leaf_grandparent && m != 0u) {
                     // into the nearest of the grandchildren that are hit; the others wait in slot order
                     const float d0 = hit0 ? tn0 : __builtin_inff(), d1 = hit1 ? tn1 : __builtin_inff();
@@ -1164,6 +1165,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                     }
                 }
             }
+            if (COUNT) n_empty += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(empty_step));
             waiting_mask = __builtin_amdgcn_ballot_w64((w & 15u) != 0u);
             walking_mask = __builtin_amdgcn_ballot_w64(w <= kFifo - 1u);
             if (!walking_mask || (uint32_t)__popcll(waiting_mask) >= p.leaf_threshold) break;
@@ -1172,6 +1174,8 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
 
         // 3. triangle round once enough lanes have a leaf waiting (or nobody can walk any more)
         if (waiting_mask && ((uint32_t)__popcll(waiting_mask) >= p.leaf_threshold || !walking_mask)) {
+            if (COUNT) n_rounds += 1u;
+            bool tested = false;                           // COUNT: this lane tests a leaf in this round
             if ((w & 15u) != 0u) {
                 // the oldest entry's next leaf; the entry goes when its last leaf is taken or its leaves lie beyond reach
                 const uint2 e = s_fifo[wait_head * 256u];
@@ -1185,7 +1189,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                     w--;
                 }
                 if (in_reach) {
-                    if (COUNT) n_leaves += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(true));
+                    if (COUNT) tested = true;
                     const float4* t = reinterpret_cast<const float4*>(leaf_bytes + (size_t)leaf * 128u);      // few per ray: 64-bit offsets cost nothing here
                     const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
                     const float2 places = *reinterpret_cast<const float2*>(t + 5);      // of the two triangles in the reference's order
@@ -1226,6 +1230,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                     }
                 }
             }
+            if (COUNT) n_leaves += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tested));
         }
 
         // 4. a finished ray leaves its closest hit behind and frees the lane

@@ -478,8 +478,10 @@ def test_walk_stats_count_the_walk_on_the_second_hierarchy(device, oracle):
         g = _render_both(device, oracle, sc, 128, 72, 3, kernel=KERNEL_SPATIAL)
     finally:
         device.lib.rt_device_set_walk_stats(device.handle, None)
-    steps, empty, leaves, _ = [int(x) for x in buf.download(np.uint64, 4)]
+    steps, empty, leaves, packed = [int(x) for x in buf.download(np.uint64, 4)]
     buf.free()
+    turns, rounds = packed & ((1 << 40) - 1), packed >> 40
+    assert 0 < steps <= 64 * turns and 0 < leaves <= 64 * rounds, "at most 64 lanes work in a turn or a round"
     assert g[2].view(np.uint32).tobytes() == g[3].view(np.uint32).tobytes()
     rays = 128 * 72 * 3
     print("per ray: %.1f steps (%.1f without a hit), %.1f leaves; the reference's walk: %.1f box tests" %
