@@ -200,7 +200,9 @@ def main():
         aside = torch.empty_like(band) if world > 1 else None
 
         def step():
-            pipe.render(depth)                       # one frame: build, camera rays, `depth` bounces
+            # one frame: build, camera rays, `depth` bounces, the final image once (the reference's Render() also
+            # refreshes its display after every bounce; nothing consumes those previews here)
+            pipe.render(depth, previews=False)
             if world > 1:
                 stream.wait_stream(comm)             # the previous frame's rows have left the copy
                 aside.copy_(band, non_blocking=True)
@@ -337,6 +339,7 @@ def main():
                    if not (args.triangles or args.width or args.height) else
                    "custom: synthetic %d-triangle scene, %dx%d, %d ray/pixel, %d bounces, LBVH rebuilt every frame" % (ntri, width, height, rpp, depth),
                    "triangles": ntri, "width": width, "height": height, "rays_per_pixel": rpp, "bounces": depth,
+                   "final_image": "once per frame (after the last bounce)",
                    "parallelism": "image rows dealt to %d GPU(s) in turn, replicated scene + per-GPU rebuild, gather to rank 0" % world},
         "lbvh_build_ms": round(avg_build_ms, 4),
         "roofline": roofline,

@@ -24,6 +24,7 @@ struct rth_settings
 	int32_t dynamic_scene;
 	int32_t reference_order_walk;
 	int32_t drop_missed_rays;
+	int32_t no_previews;
 	uint32_t device_rank, device_count;
 };
 
@@ -120,6 +121,7 @@ static Settings ToSettings(const rth_settings* s)
 	r.DynamicScene = s->dynamic_scene != 0;
 	r.ReferenceOrderWalk = s->reference_order_walk != 0;
 	r.DropMissedRays = s->drop_missed_rays != 0;
+	r.PreviewEveryBounce = s->no_previews == 0;
 	r.DeviceRank = s->device_rank;
 	r.DeviceCount = s->device_count ? s->device_count : 1;
 	return r;

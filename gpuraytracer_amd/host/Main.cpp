@@ -5,7 +5,7 @@
 //   rt_headless [--scene file.obj | --synthetic N] [--width W] [--height H] [--rpp R] [--depth D]
 //               [--cycles C] [--no-bvh] [--per-shader-build] [--rebuild] [--camera px py pz fx fy fz]
 //               [--seed S] [--gpu G] [--out image.ppm|image.png] [--pfm image.pfm] [--dynamic] [--reference-walk]
-//               [--resume state.bin] [--save-state state.bin] [--dedup] [--drop-missed-rays]
+//               [--resume state.bin] [--save-state state.bin] [--dedup] [--drop-missed-rays] [--no-previews]
 //               [--ranks N]
 //
 // --ranks N renders on GPUs G .. G + N - 1, one host thread and one RaytracerPipeline per GPU (the reference drives its
@@ -161,6 +161,7 @@ int main(int argc, char** argv)
 		else if (!std::strcmp(argv[i], "--reference-walk")) rtSettings.ReferenceOrderWalk = true;
 		else if (!std::strcmp(argv[i], "--dedup")) rtSettings.DeduplicateVertices = true;
 		else if (!std::strcmp(argv[i], "--drop-missed-rays")) rtSettings.DropMissedRays = true;
+		else if (!std::strcmp(argv[i], "--no-previews")) rtSettings.PreviewEveryBounce = false;
 		else if (!std::strcmp(argv[i], "--resume")) rtOptions.sResume = Next();
 		else if (!std::strcmp(argv[i], "--save-state")) rtOptions.sSaveState = Next();
 		else if (!std::strcmp(argv[i], "--ranks")) rtOptions.iRanks = std::atoi(Next());

@@ -636,8 +636,12 @@ namespace RT::GraphicsAPI
 		if (!(m_rtTraceRays->Render(m_rtSettings.UseBVH ? m_rtBuildBVH->GetBVH() : nullptr,
 			(m_rtSettings.UseBVH && m_rtSettings.FusedBuild) ? m_rtBuildBVH->GetAccel() : nullptr))) return false;
 
-		//the accumulated image takes the cycle's result when the cycle is complete
-		if (!(m_rtImageGeneration->Render(m_iIteration == 0))) return false;
+		//the accumulated image takes the cycle's result when the cycle is complete; in between the kernel only refreshes the
+		//displayed image, which a headless caller may not want (PreviewEveryBounce)
+		if (m_iIteration == 0 || m_rtSettings.PreviewEveryBounce)
+		{
+			if (!(m_rtImageGeneration->Render(m_iIteration == 0))) return false;
+		}
 		return true;
 	}
 

@@ -61,6 +61,8 @@ namespace RT
 		                                    //(RT_TRACE_KERNEL_QUAD) instead of the default on the library's own hierarchy
 		bool DropMissedRays = false;        //leave rays that have missed out of the later bounces of their sample cycle instead of
 		                                    //tracing them again as the reference does (same image, less work; rt_device_set_drop_missed_rays)
+		bool PreviewEveryBounce = true;     //the reference shows the running image after every Render() call (one bounce); false = the
+		                                    //final-image kernel runs only when a sample cycle is complete (same accumulated image)
 		bool DeduplicateVertices = false;   //LoadMeshFromFile merges equal vertices (the loop the reference has switched off)
 		uint32_t DeviceRank = 0;            //multi-GPU: this pipeline renders the image rows DeviceRank, DeviceRank + DeviceCount, ...
 		uint32_t DeviceCount = 1;           //(one pipeline per GPU, same scene and seeds on each; RaytracerPipeline::GatherOutput assembles the image)

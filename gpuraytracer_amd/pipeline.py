@@ -184,8 +184,10 @@ class Pipeline:
         capi.check(self.lib.rt_generate_final_image(self.dev.handle, C.byref(self.im), self.emitted.handle, self.result.handle,
                                                     self.output.handle, None), "rt_generate_final_image")
 
-    def render(self, calls=1):
-        """One call = one bounce, as RaytracerPipeline::Render."""
+    def render(self, calls=1, previews=True):
+        """One call = one bounce, as RaytracerPipeline::Render. previews=False leaves out the final-image kernel
+        between the bounces of a sample cycle, where it only refreshes the displayed image (the accumulated image
+        and the display after the cycle's last bounce are the same either way)."""
         for _ in range(calls):
             if self.use_bvh and (not self.built or (self.rebuild_every_cycle and self.iteration == 0)):
                 self.build()
@@ -195,7 +197,8 @@ class Pipeline:
             if self.iteration == self.depth:
                 self.iteration = 0
             self.trace()
-            self.final_image(self.iteration == 0)
+            if previews or self.iteration == 0:
+                self.final_image(self.iteration == 0)
 
     # ---- readback ----
     def output_image(self):

@@ -480,6 +480,33 @@ def test_resume_continues_the_random_sequences(device, oracle, tmp_path):
         b.close()
 
 
+def test_previews_between_bounces_change_no_image(device, oracle):
+    """Settings::PreviewEveryBounce = false (Pipeline.render(previews=False)): the final-image kernel only after the last
+    bounce of a sample cycle. Accumulated image, displayed image and sample count after whole cycles are those of the
+    reference's sequence, which runs the kernel after every bounce."""
+    from gpuraytracer_amd import host_py, scenes
+    from gpuraytracer_amd.pipeline import Pipeline
+    n, w, h, depth, cycles = 4000, 64, 36, 3, 3
+    cam = scenes.synthetic_scene(n)["camera"]
+    got = []
+    for previews in (True, False):
+        hp = host_py.HostPipeline(device, n, w, h, cam, seed_raygen=1, seed_trace=2, previews=previews)
+        hp.render(cycles * depth)
+        got.append((hp.result().tobytes(), hp.output().tobytes(), hp.num_samples()))
+        hp.close()
+    assert got[0] == got[1] and got[0][2] == cycles + 1
+    sc = scenes.synthetic_scene(n)
+    iv, ip = host_py.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], w / h, cam["near_z"], cam["far_z"])
+    images = []
+    for previews in (True, False):
+        rs, ts = _seeds(oracle, cycles, depth)
+        p = Pipeline(device, sc, w, h, iv, ip, depth=depth, raygen_seeds=lambda: next(rs), trace_seeds=lambda: next(ts))
+        p.render(cycles * depth, previews=previews)
+        images.append((p.result_image().tobytes(), p.output_image().tobytes()))
+        p.close()
+    assert images[0] == images[1]
+
+
 # ------------------------------------------------------------------ multi-GPU entry points of the C-ABI ----
 
 @pytest.mark.parametrize("world,w,h", [(1, 33, 9), (2, 64, 36), (3, 50, 31), (8, 130, 67), (16, 7, 5)])
