@@ -369,8 +369,8 @@ def main():
         out["roofline"]["own_layout"] = {
             "steps_per_ray": round(walk[0] / (local_rays * launches), 2), "empty_steps_per_ray": round(walk[1] / (local_rays * launches), 2),
             "leaves_per_ray": round(walk[2] / (local_rays * launches), 2), "bytes_per_launch": int(own_bytes),
-            "lanes_per_walking_turn": round(walk[0] / max(walk[3] & ((1 << 40) - 1), 1), 1),
-            "lanes_per_triangle_round": round(walk[2] / max(walk[3] >> 40, 1), 1),
+            "lanes_per_walking_turn": round(walk[0] / max(walk[3] & ((1 << 32) - 1), 1), 1),
+            "lanes_per_triangle_round": round(walk[2] / max(walk[3] >> 32, 1), 1),
             "requested_gbps": round(own_bytes / avg_trace_s / 1e9, 2),
             "note": "bytes the kernel requests in its own data layout (mostly L1/L2 hits: requested, not fetched - compare "
                     "with `traffic`); not a roofline fraction"}

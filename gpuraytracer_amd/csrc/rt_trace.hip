@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                     atomicAdd(walk_stats, (unsigned long long)n_steps);
                     atomicAdd(walk_stats + 1, (unsigned long long)n_empty);
                     atomicAdd(walk_stats + 2, (unsigned long long)n_leaves);
-                    atomicAdd(walk_stats + 3, (unsigned long long)n_turns | ((unsigned long long)n_rounds << 40));
+                    atomicAdd(walk_stats + 3, (unsigned long long)n_turns | ((unsigned long long)n_rounds << 32));
                 }
                 break;
             }

@@ -148,9 +148,10 @@ int rt_device_set_trace_tuning(rt_device* dev, const rt_trace_tuning* tuning);  
 int rt_device_listed_rays(rt_device* dev, uint32_t* count);
 /* Instrumentation (no counterpart in the reference): while a 32-byte buffer is set, every launch of the SPATIAL kernel
  * adds {steps (one 64-byte record read and four boxes tested each), steps that hit none of the four, leaves whose
- * triangles were tested, turns of the waves' walking loops | triangle rounds of the waves << 40} as four uint64 to
+ * triangles were tested, turns of the waves' walking loops | triangle rounds of the waves << 32} as four uint64 to
  * it; NULL turns it off. The kernel's own algorithmic bytes come from the first three; steps / (64 * turns) and
- * leaves / (64 * rounds) are the shares of a wave's 64 lanes at work in a walking turn and in a triangle round. */
+ * leaves / (64 * rounds) are the shares of a wave's 64 lanes at work in a walking turn and in a triangle round
+ * (the two halves of the fourth word hold 2^32 each: clear the buffer before they fill). */
 int rt_device_set_walk_stats(rt_device* dev, rt_buffer* stats);
 /* Instrumentation (no counterpart in the reference): while enabled, every trace launch brackets its traversal
  * kernel with a pair of events on the device's stream. rt_device_traverse_timing waits for the pairs recorded

@@ -22,7 +22,7 @@ for bounce in range(4):
     p.render(1)
     dev.sync()
     steps, empty, leaves, packed = [int(x) for x in buf.download(np.uint64, 4)]
-    turns, rounds = packed & ((1 << 40) - 1), packed >> 40
+    turns, rounds = packed & ((1 << 32) - 1), packed >> 32
     rays = w * h
     print("bounce %d: %.1f steps/ray (%.1f empty), %.2f leaves/ray; %.1f lanes per walking turn, %.1f lanes per triangle round; per 64 rays %.0f turns, %.1f rounds"
           % (bounce, steps / rays, empty / rays, leaves / rays, steps / max(turns, 1), leaves / max(rounds, 1), turns / (rays / 64), rounds / (rays / 64)), flush=True)

@@ -480,7 +480,7 @@ def test_walk_stats_count_the_walk_on_the_second_hierarchy(device, oracle):
         device.lib.rt_device_set_walk_stats(device.handle, None)
     steps, empty, leaves, packed = [int(x) for x in buf.download(np.uint64, 4)]
     buf.free()
-    turns, rounds = packed & ((1 << 40) - 1), packed >> 40
+    turns, rounds = packed & ((1 << 32) - 1), packed >> 32
     assert 0 < steps <= 64 * turns and 0 < leaves <= 64 * rounds, "at most 64 lanes work in a turn or a round"
     assert g[2].view(np.uint32).tobytes() == g[3].view(np.uint32).tobytes()
     rays = 128 * 72 * 3
