@@ -366,3 +366,21 @@ def test_no_kernel_uses_scratch():
         assert r.get("ScratchSize [bytes/lane]", 0) == 0 and r.get("VGPRs Spill", 0) == 0, "%s uses scratch: %s" % (name, r)
     walk = [r for n, r in kernels.items() if "k_traverse_spatialILb0" in n]
     assert len(walk) == 1 and walk[0]["Occupancy [waves/SIMD]"] >= 4
+
+
+def test_counter_file_of_the_round_travels_with_the_tree():
+    """bench.py takes its roofline fractions from the committed counter passes under profiles/: the file of this round
+    exists, names the default traversal kernel, and nothing keeps profiles/ from being sent to the GPU box."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    counters, source = bench.load_pmc("c3", "k_traverse_spatial")
+    assert counters is not None and source.startswith("profiles/")
+    assert "FETCH_SIZE" in counters and "WRITE_SIZE" in counters
+    fr = bench.counter_fractions(counters, 4.7e-3)
+    assert 0.0 < fr["memory"]["frac"] <= 1.0 and 0.0 < fr["vector"]["frac"] <= 1.0
+    ignore = os.path.join(ROOT, ".gpurunignore")
+    if os.path.exists(ignore):
+        lines = [l.strip() for l in open(ignore) if l.strip()]
+        assert not any(l.strip("./").startswith("profiles") for l in lines)
