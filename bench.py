@@ -345,7 +345,7 @@ def main():
         "roofline": roofline,
         # 252 B per triangle (reference layout) over the time a frame pays for its build - both hierarchies, and for a
         # moving scene also the animation and the bounds - and, below, over the reference's hierarchy alone
-        "build_roofline": {"kernels": "per frame: k_morton_packed, radix passes, k_leaves, k_upsweep for the reference's hierarchy; "
+        "build_roofline": {"kernels": "per frame: k_morton_hist, radix passes, k_leaves, k_upsweep for the reference's hierarchy; "
                                       "keys, radix passes, cell layout, k_leaves, k_upsweep for the library's own",
                            "bound": "hbm", "achieved": round(build_bytes / (avg_build_ms * 1e-3) / 1e9, 1),
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -197,21 +197,6 @@ __global__ __launch_bounds__(256) void k_animate(uint32_t n, uint32_t frame, con
     }
 }
 
-// dbounds (optional): scene bounds in device memory, (min.xyz, pad, max.xyz, pad); overrides sb
-__global__ __launch_bounds__(256) void k_morton_packed(SceneBounds sb, const float* __restrict__ dbounds, uint32_t n,
-                                                       const float4* __restrict__ tris, uint2* __restrict__ keys) {
-    uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n) return;
-    if (dbounds) {
-        sb.mn[0] = dbounds[0]; sb.mn[1] = dbounds[1]; sb.mn[2] = dbounds[2];
-        sb.mx[0] = dbounds[4]; sb.mx[1] = dbounds[5]; sb.mx[2] = dbounds[6];
-    }
-    uint32_t ci = t * 3u;
-    float4 a = tris[ci], b = tris[ci + 1], c = tris[ci + 2];
-    uint32_t code = morton_code(a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, sb.mn, sb.mx);
-    keys[t] = make_uint2(code, ci);
-}
-
 // Keys of the library's own hierarchy, and every triangle's place in the reference's order: entry r of the
 // sorted reference pairs names triangle ci / 3; its key is the interleave of the same ten bits per axis the
 // reference quantises the centroid to (CS_GenerateMortonCodes.hlsl:58-66), without the overlap of the reference's
@@ -582,6 +567,37 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t* __restrict
         }
     }
     if (REF && tile == 0u) freq[tid].x = 0u;      // shader/CS_SortSort.hlsl:34
+}
+
+// Morton codes of the packed triangles (CS_GenerateMortonCodes.hlsl:58-66) and the first sorting pass's k_sort_hist in
+// one: a workgroup makes the (code, 3 * triangle) keys of one sorting tile (the 256 x kItems layout k_sort_hist reads)
+// and counts their lowest digits while it has them.
+// dbounds (optional): scene bounds in device memory, (min.xyz, pad, max.xyz, pad); overrides sb
+__global__ __launch_bounds__(256) void k_morton_hist(SceneBounds sb, const float* __restrict__ dbounds, uint32_t n,
+                                                     const float4* __restrict__ tris, uint2* __restrict__ keys,
+                                                     uint32_t* __restrict__ table, uint32_t tiles) {
+    __shared__ uint32_t hist[4][256];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    hist[0][tid] = 0u; hist[1][tid] = 0u; hist[2][tid] = 0u; hist[3][tid] = 0u;
+    if (dbounds) {
+        sb.mn[0] = dbounds[0]; sb.mn[1] = dbounds[1]; sb.mn[2] = dbounds[2];
+        sb.mx[0] = dbounds[4]; sb.mx[1] = dbounds[5]; sb.mx[2] = dbounds[6];
+    }
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (uint32_t)kTile;
+#pragma unroll
+    for (int j = 0; j < kItems; j++) {
+        const uint32_t t = base + (uint32_t)j * 256u + tid;
+        if (t < n) {
+            const uint32_t ci = t * 3u;
+            const float4 a = tris[ci], b = tris[ci + 1], c = tris[ci + 2];
+            const uint32_t code = morton_code(a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z, sb.mn, sb.mx);
+            keys[t] = make_uint2(code, ci);
+            atomicAdd(&hist[wave][code & 0xffu], 1u);
+        }
+    }
+    __syncthreads();
+    table[(size_t)tid * tiles + blockIdx.x] = hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid];
 }
 
 // ------------------------------------------------------------------- hierarchy ----
@@ -1075,7 +1091,7 @@ int rt_accel_pairs(rt_accel* a, bool own, const rt_aabb* nodes, const float4** p
     return rt_launch_status();
 }
 
-int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted) {
+int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted, bool first_counted) {
     int rc = rt_sort_workspace(dev, n);
     if (rc) return rc;
     hipStream_t s = dev->stream;
@@ -1084,8 +1100,10 @@ int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passe
     uint2* dst = b;
     for (uint32_t pass = 0; pass < passes; pass++) {
         const uint32_t shift = 8u * pass;
-        hipLaunchKernelGGL((k_sort_hist<2, false>), dim3(tiles), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)nullptr, n,
-                           shift, dev->sort_table, tiles, (uint4*)nullptr);
+        // (first_counted: the kernel that made the keys has left the first pass's per-tile counts in the table)
+        if (pass || !first_counted)
+            hipLaunchKernelGGL((k_sort_hist<2, false>), dim3(tiles), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)nullptr, n,
+                               shift, dev->sort_table, tiles, (uint4*)nullptr);
         hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, s, dev->sort_table, tiles, dev->sort_totals);
         hipLaunchKernelGGL((k_sort_scatter<2, 2, false>), dim3(tiles), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, n,
                            shift, dev->sort_table, tiles, dev->sort_totals, (uint4*)nullptr);
@@ -1412,8 +1430,11 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     hipStream_t s = dev->stream;
     dev->missed_valid = false;          // a new hierarchy: rays that missed the old scene may hit this one
 
-    hipLaunchKernelGGL(k_morton_packed, dim3(div_up(n, 256u)), dim3(256), 0, s, make_bounds(scene_min, scene_max), dbounds, n,
-                       a->tris, a->keys_a);
+    rc = rt_sort_workspace(dev, n);
+    if (rc) return rc;
+    const uint32_t tiles = div_up(n, kTile);
+    hipLaunchKernelGGL(k_morton_hist, dim3(tiles), dim3(256), 0, s, make_bounds(scene_min, scene_max), dbounds, n, a->tris, a->keys_a,
+                       dev->sort_table, tiles);
     // The library's own hierarchy (rt_accel_set_second_hierarchy): same triangles, same kernels, keys without overlapping
     // bits. Its keys' coordinates come from per-axis histograms of the centroids, which only need the triangles:
     const bool own = a->want_spatial && a->sp_tris != nullptr;
@@ -1426,7 +1447,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
         hipLaunchKernelGGL(k_axis_map, dim3(3), dim3(1024), 0, s, samples, a->cells);
     }
     uint2* src = nullptr;
-    rc = rt_sort_pairs(dev, a->keys_a, a->keys_b, n, 4u, &src);     // four passes: the sorted pairs are back in keys_a
+    rc = rt_sort_pairs(dev, a->keys_a, a->keys_b, n, 4u, &src, true);     // four passes: the sorted pairs are back in keys_a
     if (rc) return rc;
     uint2* other = src == a->keys_a ? a->keys_b : a->keys_a;
     const uint32_t leaves = lv.n[0];

@@ -117,7 +117,7 @@ int rt_static_scratch_init(int gpu);
 const char* rt_comm_error_string(int code);
 // Stable LSD radix sort of (key, value) pairs by the low 8 * passes key bits, queued on the device's stream.
 // a and b hold n pairs each and are both overwritten; *sorted receives whichever of them holds the result.
-int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted);
+int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted, bool first_counted = false);
 // Writes the private copy (interleaved sibling pairs, Morton-ordered packed triangles: see rt_levels and
 // rt_accel) of a hierarchy held in the reference's layout. pairs: rt_aligned_node_slots() slots;
 // sorted_tris: 5 float4 per leaf.
