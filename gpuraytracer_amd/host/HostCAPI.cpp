@@ -2,6 +2,7 @@
 // through ctypes. Not part of the gpurt device ABI: these only forward to the classes next to them.
 
 #include <cstring>
+#include <iostream>
 #include <vector>
 
 #include "RaytracerPipeline.h"
@@ -45,6 +46,13 @@ float rth_parse_real(const char* text) { return ParseReal(text, text + std::strl
 MeshInfo* rth_load_mesh_dedup(const char* path)
 {
 	MeshInfo m = LoadMeshFromFile(path, true);
+	if (!m.Vertices) return nullptr;
+	return new MeshInfo(m);
+}
+MeshInfo* rth_load_mesh_threads(const char* path, int dedup, uint32_t threads)
+{
+	MeshInfo m = LoadMeshFromFile(path, dedup != 0, threads);
+	std::cout.flush();		//the loader's messages, before the caller goes on writing to the same descriptor
 	if (!m.Vertices) return nullptr;
 	return new MeshInfo(m);
 }

@@ -5,7 +5,7 @@
 //   rt_headless [--scene file.obj | --synthetic N] [--width W] [--height H] [--rpp R] [--depth D]
 //               [--cycles C] [--no-bvh] [--per-shader-build] [--rebuild] [--camera px py pz fx fy fz]
 //               [--seed S] [--gpu G] [--out image.ppm|image.png] [--pfm image.pfm] [--dynamic] [--reference-walk]
-//               [--resume state.bin] [--save-state state.bin] [--dedup] [--drop-missed-rays] [--no-previews]
+//               [--resume state.bin] [--save-state state.bin] [--dedup] [--loader-threads T] [--drop-missed-rays] [--no-previews]
 //               [--ranks N]
 //
 // --ranks N renders on GPUs G .. G + N - 1, one host thread and one RaytracerPipeline per GPU (the reference drives its
@@ -67,7 +67,7 @@ namespace
 
 		MeshInfo rtMesh{};
 		if (rtOptions.iSynthetic) { rtMesh = GenerateSyntheticScene(rtOptions.iSynthetic); ApplySyntheticCamera(rtSettings); }
-		else rtMesh = LoadMeshFromFile(rtSettings.SceneFilename, rtSettings.DeduplicateVertices);
+		else rtMesh = LoadMeshFromFile(rtSettings.SceneFilename, rtSettings.DeduplicateVertices, rtSettings.LoaderThreads);
 		if (!rtMesh.Vertices) { Say("Error while loading the scene"); return 1; }
 		const uint64_t iTriangles = rtMesh.IndexCount / 3;
 
@@ -160,6 +160,7 @@ int main(int argc, char** argv)
 		else if (!std::strcmp(argv[i], "--dynamic")) rtSettings.DynamicScene = true;
 		else if (!std::strcmp(argv[i], "--reference-walk")) rtSettings.ReferenceOrderWalk = true;
 		else if (!std::strcmp(argv[i], "--dedup")) rtSettings.DeduplicateVertices = true;
+		else if (!std::strcmp(argv[i], "--loader-threads")) rtSettings.LoaderThreads = (uint32_t)std::atoi(Next());
 		else if (!std::strcmp(argv[i], "--drop-missed-rays")) rtSettings.DropMissedRays = true;
 		else if (!std::strcmp(argv[i], "--no-previews")) rtSettings.PreviewEveryBounce = false;
 		else if (!std::strcmp(argv[i], "--resume")) rtOptions.sResume = Next();

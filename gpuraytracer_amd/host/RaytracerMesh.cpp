@@ -13,6 +13,10 @@
 
 #include "RaytracerMesh.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cmath>
@@ -20,7 +24,9 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <new>
 #include <sstream>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -28,6 +34,34 @@ namespace RT::GraphicsAPI
 {
 	namespace
 	{
+		//Large arrays of the loader come straight from the kernel: blocks of this size taken from malloc by several threads
+		//at once end up in per-thread heaps that grow a few pages per system call, which costs more than the parsing.
+		template <typename T> struct MapAllocator
+		{
+			typedef T value_type;
+			static constexpr size_t kDirect = 1u << 20;
+			MapAllocator() = default;
+			template <typename U> MapAllocator(const MapAllocator<U>&) {}
+			T* allocate(size_t n)
+			{
+				const size_t iBytes = n * sizeof(T);
+				if (iBytes < kDirect) return static_cast<T*>(::operator new(iBytes));
+				void* p = mmap(nullptr, iBytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+				if (p == MAP_FAILED) throw std::bad_alloc();
+				(void)madvise(p, iBytes, MADV_HUGEPAGE);
+				return static_cast<T*>(p);
+			}
+			void deallocate(T* p, size_t n)
+			{
+				const size_t iBytes = n * sizeof(T);
+				if (iBytes < kDirect) ::operator delete(p);
+				else munmap(p, iBytes);
+			}
+			template <typename U> bool operator==(const MapAllocator<U>&) const { return true; }
+			template <typename U> bool operator!=(const MapAllocator<U>&) const { return false; }
+		};
+		template <typename T> using BigVector = std::vector<T, MapAllocator<T>>;
+
 		inline Float3 Add(Float3 a, Float3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
 		inline Float3 Sub(Float3 a, Float3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
 		inline Float3 Scale(Float3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
@@ -193,9 +227,13 @@ namespace RT::GraphicsAPI
 
 		bool ReadFile(const std::string& sFileName, std::vector<uint8_t>& stdBytes)
 		{
-			std::ifstream stdFile(sFileName, std::ios::binary);
+			std::ifstream stdFile(sFileName, std::ios::binary | std::ios::ate);
 			if (!stdFile) return false;
-			stdBytes.assign(std::istreambuf_iterator<char>(stdFile), std::istreambuf_iterator<char>());
+			const std::streamoff iSize = (std::streamoff)stdFile.tellg();
+			if (iSize < 0) return false;
+			stdBytes.resize((size_t)iSize);
+			stdFile.seekg(0);
+			if (iSize > 0 && !stdFile.read((char*)stdBytes.data(), iSize)) return false;
 			return true;
 		}
 
@@ -282,29 +320,56 @@ namespace RT::GraphicsAPI
 			return true;
 		}
 
-		//"v", "v/vt", "v//vn", "v/vt/vn"; returns false on a malformed or zero index
-		bool ParseFaceVertex(const char*& p, int iNumV, int iNumVT, int iNumVN, int iOut[3])
+		//one corner of a face as written: "v", "v/vt", "v//vn", "v/vt/vn" (the numbers as they stand, and which are there)
+		struct RawCorner
 		{
-			auto Fix = [](int i, int n, int& iResult) { if (i > 0) { iResult = i - 1; return true; } if (i == 0) return false; iResult = n + i; return true; };
-			iOut[0] = iOut[1] = iOut[2] = -1;
-			if (!Fix(std::atoi(p), iNumV, iOut[0])) return false;
+			int Raw[3];
+			uint8_t Has;		//bit k: Raw[k] was written
+		};
+
+		RawCorner ParseFaceVertexRaw(const char*& p)
+		{
+			RawCorner c{ { 0, 0, 0 }, 1 };
+			c.Raw[0] = std::atoi(p);
 			p += std::strcspn(p, "/ \t\r");
-			if (*p != '/') return true;
+			if (*p != '/') return c;
 			p++;
 			if (*p == '/')
 			{
 				p++;
-				if (!Fix(std::atoi(p), iNumVN, iOut[2])) return false;
+				c.Raw[2] = std::atoi(p); c.Has |= 4;
 				p += std::strcspn(p, "/ \t\r");
-				return true;
+				return c;
 			}
-			if (!Fix(std::atoi(p), iNumVT, iOut[1])) return false;
+			c.Raw[1] = std::atoi(p); c.Has |= 2;
 			p += std::strcspn(p, "/ \t\r");
-			if (*p != '/') return true;
+			if (*p != '/') return c;
 			p++;
-			if (!Fix(std::atoi(p), iNumVN, iOut[2])) return false;
+			c.Raw[2] = std::atoi(p); c.Has |= 4;
 			p += std::strcspn(p, "/ \t\r");
+			return c;
+		}
+
+		//1-based or relative to the counts so far -> 0-based (-1: not written); false on a zero index
+		bool FixCorner(const RawCorner& c, int iNumV, int iNumVT, int iNumVN, int iOut[3])
+		{
+			const int n[3] = { iNumV, iNumVT, iNumVN };
+			iOut[0] = iOut[1] = iOut[2] = -1;
+			for (int k = 0; k < 3; k++)
+			{
+				if (!(c.Has & (1 << k))) continue;
+				if (c.Raw[k] > 0) iOut[k] = c.Raw[k] - 1;
+				else if (c.Raw[k] == 0) return false;
+				else iOut[k] = n[k] + c.Raw[k];
+			}
 			return true;
+		}
+
+		//returns false on a malformed or zero index
+		bool ParseFaceVertex(const char*& p, int iNumV, int iNumVT, int iNumVN, int iOut[3])
+		{
+			const RawCorner c = ParseFaceVertexRaw(p);
+			return FixCorner(c, iNumV, iNumVT, iNumVN, iOut);
 		}
 
 		void GetTexture(const std::string& sTextureName, std::unordered_map<std::string, uint32_t>& stdTextureNames)
@@ -466,6 +531,32 @@ namespace RT::GraphicsAPI
 		}
 	}
 
+	//CalculateNormals (if asked) and CalculateTangents for triangles [iFrom, iTo) of a mesh whose vertices 3t, 3t + 1, 3t + 2 belong
+	//to triangle t alone: the sums of the loops above have one term each (added to zero as there, which turns -0 into +0)
+	static void CalculateTangentSpaceOfSoup(MeshInfo* ionMeshInfo, bool bNormals, uint64_t iFrom, uint64_t iTo)
+	{
+		const Float3 xmZero{ 0.0f, 0.0f, 0.0f };
+		for (uint64_t t = iFrom; t < iTo; t++)
+		{
+			Vertex& v1 = ionMeshInfo->Vertices[3 * t]; Vertex& v2 = ionMeshInfo->Vertices[3 * t + 1]; Vertex& v3 = ionMeshInfo->Vertices[3 * t + 2];
+			if (bNormals)
+			{
+				const Float3 n = NormalizeOrZero(Add(xmZero, Cross(Sub(v2.Position, v1.Position), Sub(v3.Position, v1.Position))));
+				v1.Normal = n; v2.Normal = n; v3.Normal = n;
+			}
+			const Float3 e1 = Sub(v2.Position, v1.Position), e2 = Sub(v3.Position, v1.Position);
+			const float t1x = v2.UV.x - v1.UV.x, t1y = v2.UV.y - v1.UV.y, t2x = v3.UV.x - v1.UV.x, t2y = v3.UV.y - v1.UV.y;
+			const float fDenominator = t1x * t2y - t1y * t2x;
+			const Float3 xmNominator = Sub(Scale(e1, t2y), Scale(e2, t1y));
+			const float fEpsilon = 1.192092896e-7f;
+			Float3 xmTangent{ 0.0f, 0.0f, 0.0f };
+			if (!(fDenominator <= fEpsilon && fDenominator >= -fEpsilon))
+				xmTangent = { xmNominator.x / fDenominator, xmNominator.y / fDenominator, xmNominator.z / fDenominator };
+			const Float3 g = NormalizeOrZero(Add(xmZero, xmTangent));
+			v1.Tangent = g; v2.Tangent = g; v3.Tangent = g;
+		}
+	}
+
 	//bounds over triangle centroids, (p1 + p2 + p3) * (1/3), starting from +-FLT_MAX (src/RaytracerMesh.cpp:342-364 of the reference)
 	AABB CalculateCentroidBounds(const MeshInfo& rtMesh)
 	{
@@ -491,26 +582,25 @@ namespace RT::GraphicsAPI
 	//accepts, or becomes a new unique vertex. Equality of floats makes -0 equal +0 and a NaN unequal to everything, so the
 	//hash key holds the components with -0 turned into +0, and a vertex with a NaN is always unique. Expected O(n)
 	//instead of the reference's O(n^2).
-	static uint64_t DeduplicateVertices(const std::vector<Vertex>& stdVertices, Index* rtIndices, std::vector<Vertex>& stdUnique)
+	//With several threads: the vertices are dealt to the threads by their hash, every thread finds the first occurrence
+	//of each of ITS vertices (equal vertices have equal hashes, so they meet in one thread), and the unique vertices are
+	//then numbered in the order of their first occurrence - the numbering of the loop above.
+	namespace
 	{
-		struct Key { uint32_t w[9]; bool operator==(const Key& o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; } };
-		struct KeyHash
+		struct VertexKey { uint32_t w[9]; bool operator==(const VertexKey& o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; } };
+		struct VertexKeyHash
 		{
-			size_t operator()(const Key& k) const
+			size_t operator()(const VertexKey& k) const
 			{
 				uint64_t h = 0xcbf29ce484222325ull;
 				for (uint32_t x : k.w) { h ^= x; h *= 0x100000001b3ull; h ^= h >> 29; }
 				return (size_t)h;
 			}
 		};
-		std::unordered_map<Key, Index, KeyHash> stdFirst;
-		stdFirst.reserve(stdVertices.size());
-		stdUnique.clear();
-		for (size_t i = 0; i < stdVertices.size(); i++)
+		//false: the vertex holds a NaN and equals nothing
+		inline bool MakeVertexKey(const Vertex& v, VertexKey& k)
 		{
-			const Vertex& v = stdVertices[i];
 			const float f[8] = { v.Position.x, v.Position.y, v.Position.z, v.UV.x, v.UV.y, v.Normal.x, v.Normal.y, v.Normal.z };
-			Key k;
 			bool bNaN = false;
 			for (int c = 0; c < 8; c++)
 			{
@@ -519,40 +609,102 @@ namespace RT::GraphicsAPI
 				std::memcpy(&k.w[c], &x, 4);
 			}
 			k.w[8] = v.MaterialID;
-			if (!bNaN)
-			{
-				auto [stdIt, bNew] = stdFirst.try_emplace(k, (Index)stdUnique.size());
-				if (!bNew) { rtIndices[i] = stdIt->second; continue; }
-			}
-			rtIndices[i] = (Index)stdUnique.size();
-			stdUnique.push_back(v);
+			return !bNaN;
 		}
-		return stdUnique.size();
+		//rtWork(t) for t = 0 .. iThreads - 1, each on a thread of its own (0 on the caller's)
+		template <typename F> void RunThreads(uint32_t iThreads, F rtWork)
+		{
+			std::vector<std::thread> stdThreads;
+			for (uint32_t t = 1; t < iThreads; t++) stdThreads.emplace_back(rtWork, t);
+			rtWork(0u);
+			for (std::thread& stdThread : stdThreads) stdThread.join();
+		}
+	}
+
+	static uint64_t DeduplicateVertices(const BigVector<Vertex>& stdVertices, Index* rtIndices, BigVector<Vertex>& stdUnique, uint32_t iThreads)
+	{
+		const size_t iCount = stdVertices.size();
+		stdUnique.clear();
+		if (iThreads <= 1)
+		{
+			std::unordered_map<VertexKey, Index, VertexKeyHash> stdFirst;
+			stdFirst.reserve(iCount);
+			for (size_t i = 0; i < iCount; i++)
+			{
+				VertexKey k;
+				if (MakeVertexKey(stdVertices[i], k))
+				{
+					auto [stdIt, bNew] = stdFirst.try_emplace(k, (Index)stdUnique.size());
+					if (!bNew) { rtIndices[i] = stdIt->second; continue; }
+				}
+				rtIndices[i] = (Index)stdUnique.size();
+				stdUnique.push_back(stdVertices[i]);
+			}
+			return stdUnique.size();
+		}
+		//hashes (0 marks a vertex with a NaN: always unique), then per thread the first occurrences among its share
+		BigVector<uint64_t> stdHash(iCount);
+		RunThreads(iThreads, [&](uint32_t t) {
+			for (size_t i = iCount * t / iThreads; i < iCount * (t + 1) / iThreads; i++)
+			{
+				VertexKey k;
+				stdHash[i] = MakeVertexKey(stdVertices[i], k) ? ((uint64_t)VertexKeyHash()(k) | 1ull) : 0ull;
+			}
+		});
+		BigVector<Index> stdFirstOf(iCount);		//index of the first vertex equal to vertex i
+		RunThreads(iThreads, [&](uint32_t t) {
+			std::unordered_map<VertexKey, Index, VertexKeyHash> stdFirst;
+			stdFirst.reserve(iCount / iThreads + 16);
+			for (size_t i = 0; i < iCount; i++)
+			{
+				const uint64_t h = stdHash[i];
+				if (h == 0ull) { if (i % iThreads == t) stdFirstOf[i] = (Index)i; continue; }
+				if ((h >> 1) % iThreads != t) continue;
+				VertexKey k;
+				MakeVertexKey(stdVertices[i], k);
+				stdFirstOf[i] = stdFirst.try_emplace(k, (Index)i).first->second;
+			}
+		});
+		//numbers of the unique vertices in the order of their first occurrence
+		BigVector<Index> stdNumber(iCount);
+		Index iUnique = 0;
+		for (size_t i = 0; i < iCount; i++) if (stdFirstOf[i] == (Index)i) stdNumber[i] = iUnique++;
+		stdUnique.resize(iUnique);
+		RunThreads(iThreads, [&](uint32_t t) {
+			for (size_t i = iCount * t / iThreads; i < iCount * (t + 1) / iThreads; i++)
+			{
+				rtIndices[i] = stdNumber[stdFirstOf[i]];
+				if (stdFirstOf[i] == (Index)i) stdUnique[stdNumber[i]] = stdVertices[i];
+			}
+		});
+		return iUnique;
 	}
 
 
-	MeshInfo LoadMeshFromFile(const std::string& sFileName, bool bDeduplicate)
+	//what both parsers hand to FinishMesh: one vertex per face corner in file order, the materials of the libraries named
+	struct ParsedOBJ
 	{
-		MeshInfo rtNothing{};
+		BigVector<Vertex> Vertices;
+		std::vector<ObjMaterial> Materials;
+		bool CalculateNormals = false;
+	};
+
+	//line by line, as the reference's parser goes through the file
+	static bool ParseOBJSerial(const std::string& sFileName, const std::string& sDirectory, ParsedOBJ& rtParsed)
+	{
+		const bool rtNothing = false;
 		std::ifstream stdFile(sFileName);
 		if (!stdFile)
 		{
 			std::cout << "Error loading scene: cannot open " << sFileName << "\n";
 			return rtNothing;
 		}
-		//the material library is looked up next to the OBJ file
-		std::string sDirectory;
-		{
-			size_t iSlash = sFileName.find_last_of("/\\");
-			if (iSlash != std::string::npos) sDirectory = sFileName.substr(0, iSlash + 1);
-		}
-
 		std::vector<float> stdPositions, stdTexcoords, stdNormals;
-		std::vector<ObjMaterial> stdMaterials;
+		std::vector<ObjMaterial>& stdMaterials = rtParsed.Materials;
 		std::unordered_map<std::string, int> stdMaterialMap;
-		std::vector<Vertex> stdVertices;
+		BigVector<Vertex>& stdVertices = rtParsed.Vertices;
 		int iCurrentMaterial = -1;
-		bool bCalculateNormals = false;
+		bool& bCalculateNormals = rtParsed.CalculateNormals;
 		std::string sLine;
 		size_t iLineNumber = 0;
 		while (std::getline(stdFile, sLine))
@@ -619,7 +771,16 @@ namespace RT::GraphicsAPI
 			}
 			//"o", "g", "s" and everything else do not change the flat triangle list
 		}
+		return true;
+	}
 
+	//duplicate removal, materials, bounds, normals and tangents (src/RaytracerMesh.cpp:243-389 of the reference)
+	static MeshInfo FinishMesh(const std::string& sFileName, ParsedOBJ& rtParsed, bool bDeduplicate, uint32_t iThreads)
+	{
+		MeshInfo rtNothing{};
+		BigVector<Vertex>& stdVertices = rtParsed.Vertices;
+		std::vector<ObjMaterial>& stdMaterials = rtParsed.Materials;
+		const bool bCalculateNormals = rtParsed.CalculateNormals;
 		const uint64_t iNumVertices = stdVertices.size();
 		if (iNumVertices == 0)
 		{
@@ -633,16 +794,21 @@ namespace RT::GraphicsAPI
 		rtMesh.Indices = new Index[iNumVertices];
 		if (bDeduplicate)
 		{
-			std::vector<Vertex> stdUnique;
-			rtMesh.VertexCount = DeduplicateVertices(stdVertices, rtMesh.Indices, stdUnique);
+			BigVector<Vertex> stdUnique;
+			rtMesh.VertexCount = DeduplicateVertices(stdVertices, rtMesh.Indices, stdUnique, iThreads);
 			rtMesh.Vertices = new Vertex[rtMesh.VertexCount];
-			for (uint64_t i = 0; i < rtMesh.VertexCount; i++) rtMesh.Vertices[i] = stdUnique[i];
+			const uint64_t iUnique = rtMesh.VertexCount;
+			RunThreads(iThreads, [&](uint32_t t) {
+				for (uint64_t i = iUnique * t / iThreads; i < iUnique * (t + 1) / iThreads; i++) rtMesh.Vertices[i] = stdUnique[i];
+			});
 		}
 		else
 		{
 			rtMesh.VertexCount = iNumVertices;
 			rtMesh.Vertices = new Vertex[iNumVertices];
-			for (uint64_t i = 0; i < iNumVertices; i++) { rtMesh.Indices[i] = (Index)i; rtMesh.Vertices[i] = stdVertices[i]; }
+			RunThreads(iThreads, [&](uint32_t t) {
+				for (uint64_t i = iNumVertices * t / iThreads; i < iNumVertices * (t + 1) / iThreads; i++) { rtMesh.Indices[i] = (Index)i; rtMesh.Vertices[i] = stdVertices[i]; }
+			});
 		}
 
 		//materials (src/RaytracerMesh.cpp:277-321 of the reference)
@@ -684,12 +850,264 @@ namespace RT::GraphicsAPI
 		for (auto& [sTextureName, iTextureIndex] : stdTextureNames) rtMesh.TextureNames[iTextureIndex] = sTextureName;
 
 		rtMesh.SceneAABB = CalculateCentroidBounds(rtMesh);
-		if (bCalculateNormals) CalculateNormals(&rtMesh);
-		CalculateTangents(&rtMesh);
+		if (!bDeduplicate && iThreads > 1)
+		{
+			//one vertex per face corner: every sum has one term, triangles are independent of each other
+			const uint64_t iTriangles = rtMesh.IndexCount / 3;
+			RunThreads(iThreads, [&](uint32_t t) { CalculateTangentSpaceOfSoup(&rtMesh, bCalculateNormals, iTriangles * t / iThreads, iTriangles * (t + 1) / iThreads); });
+		}
+		else
+		{
+			if (bCalculateNormals) CalculateNormals(&rtMesh);
+			CalculateTangents(&rtMesh);
+		}
 
 		std::cout << "Successfully loaded the scene with:\n " << rtMesh.VertexCount << " vertices\n " << rtMesh.IndexCount << " indices\n "
 			<< rtMesh.MaterialCount << " materials\n " << (rtMesh.TextureNameCount - 1) << " textures\n";
 		return rtMesh;
+	}
+
+
+	// ---- the same file parsed by several threads ----
+	//
+	//The file is cut at line ends into one piece per thread. A thread parses its piece into its own arrays and keeps, per
+	//face, the corners as written together with how many v / vt / vn lines of ITS piece came before: indices are 1-based or
+	//relative to the counts "so far", which only exist once the pieces before are counted. Statements whose effect
+	//depends on what came earlier in the file (usemtl, mtllib) are kept as events. Afterwards: counts are prefix-summed
+	//over the pieces, the events replayed in file order, the first error (lowest line) reported as the serial parser
+	//reports it, and the vertices made face by face in parallel. Same MeshInfo, bit for bit.
+	namespace
+	{
+		struct FaceRecord
+		{
+			RawCorner Corners[3];
+			uint32_t NumV, NumVT, NumVN;	//lines of the kind in this piece before the face
+			uint32_t Line;					//line of the face within the piece (from 1)
+			uint32_t NumCorners;			//3, or what was written (errors); more than 3: the fourth is in Extra
+			uint32_t Event;					//events of this piece before the face
+		};
+		struct PieceEvent { bool Library; std::string Text; };
+		struct Piece
+		{
+			const char* Begin = nullptr;
+			const char* End = nullptr;
+			BigVector<float> Positions, Texcoords, Normals;
+			BigVector<FaceRecord> Faces;
+			std::vector<std::pair<uint32_t, RawCorner>> Extra;	//(face, its fourth corner)
+			std::vector<PieceEvent> Events;
+			uint32_t Lines = 0;
+		};
+
+		void ParsePiece(Piece& rtPiece)
+		{
+			{	//lines by their first characters, so that the arrays are allocated once (a little too large: "v" needs a blank behind it)
+				size_t iV = 0, iVT = 0, iVN = 0, iF = 0;
+				for (const char* p = rtPiece.Begin; p < rtPiece.End;)
+				{
+					const char* pEol = (const char*)std::memchr(p, '\n', (size_t)(rtPiece.End - p));
+					const char* pStop = pEol ? pEol : rtPiece.End;
+					while (p < pStop && IsSpace(*p)) p++;
+					if (p + 1 < pStop)
+					{
+						if (p[0] == 'v') { if (p[1] == 't') iVT++; else if (p[1] == 'n') iVN++; else iV++; }
+						else if (p[0] == 'f') iF++;
+					}
+					p = pEol ? pEol + 1 : rtPiece.End;
+				}
+				rtPiece.Positions.reserve(iV * 3); rtPiece.Texcoords.reserve(iVT * 2); rtPiece.Normals.reserve(iVN * 3); rtPiece.Faces.reserve(iF);
+			}
+			std::string sLine;
+			const char* pAt = rtPiece.Begin;
+			while (pAt < rtPiece.End)
+			{
+				const char* pEol = (const char*)std::memchr(pAt, '\n', (size_t)(rtPiece.End - pAt));
+				const char* pNext = pEol ? pEol + 1 : rtPiece.End;
+				sLine.assign(pAt, pEol ? pEol : rtPiece.End);		//what std::getline delivers
+				pAt = pNext;
+				rtPiece.Lines++;
+				TrimLine(sLine);
+				const char* p = sLine.c_str();
+				p += std::strspn(p, " \t");
+				if (*p == '\0' || *p == '#') continue;
+				if (p[0] == 'v' && IsSpace(p[1])) { p += 2; for (int i = 0; i < 3; i++) rtPiece.Positions.push_back(NextReal(p)); continue; }
+				if (p[0] == 'v' && p[1] == 'n' && IsSpace(p[2])) { p += 3; for (int i = 0; i < 3; i++) rtPiece.Normals.push_back(NextReal(p)); continue; }
+				if (p[0] == 'v' && p[1] == 't' && IsSpace(p[2])) { p += 3; for (int i = 0; i < 2; i++) rtPiece.Texcoords.push_back(NextReal(p)); continue; }
+				if (p[0] == 'f' && IsSpace(p[1]))
+				{
+					p += 2;
+					FaceRecord f{};
+					f.NumV = (uint32_t)(rtPiece.Positions.size() / 3); f.NumVT = (uint32_t)(rtPiece.Texcoords.size() / 2);
+					f.NumVN = (uint32_t)(rtPiece.Normals.size() / 3);
+					f.Line = rtPiece.Lines; f.Event = (uint32_t)rtPiece.Events.size();
+					for (;;)
+					{
+						p += std::strspn(p, " \t");
+						if (*p == '\0' || *p == '\r') break;
+						const RawCorner c = ParseFaceVertexRaw(p);
+						if (f.NumCorners < 3) f.Corners[f.NumCorners] = c;
+						else if (f.NumCorners == 3) rtPiece.Extra.push_back({ (uint32_t)rtPiece.Faces.size(), c });
+						f.NumCorners++;
+						if (f.NumCorners == 4) break;			//the serial parser gives up at the fourth corner, one way or the other
+					}
+					rtPiece.Faces.push_back(f);
+					continue;
+				}
+				if (!std::strncmp(p, "usemtl", 6) && IsSpace(p[6])) { rtPiece.Events.push_back({ false, std::string(p + 7) }); continue; }
+				if (!std::strncmp(p, "mtllib", 6) && IsSpace(p[6])) { rtPiece.Events.push_back({ true, std::string(p + 7) }); continue; }
+			}
+		}
+
+	}
+
+	static bool ParseOBJParallel(const std::string& sFileName, const std::string& sDirectory, uint32_t iThreads, ParsedOBJ& rtParsed)
+	{
+		//the file is mapped, not read: its pages are the page cache's
+		std::vector<uint8_t> stdBytes;
+		const char* pMapped = nullptr;
+		size_t iMappedSize = 0;
+		{
+			const int iFile = open(sFileName.c_str(), O_RDONLY);
+			struct stat rtStat;
+			if (iFile >= 0 && fstat(iFile, &rtStat) == 0 && rtStat.st_size > 0)
+			{
+				void* p = mmap(nullptr, (size_t)rtStat.st_size, PROT_READ, MAP_PRIVATE, iFile, 0);
+				if (p != MAP_FAILED) { pMapped = (const char*)p; iMappedSize = (size_t)rtStat.st_size; }
+			}
+			if (iFile >= 0) close(iFile);
+		}
+		struct Unmap { const char* p; size_t n; ~Unmap() { if (p) munmap((void*)p, n); } } rtUnmap{ pMapped, iMappedSize };
+		if (!pMapped && !ReadFile(sFileName, stdBytes))
+		{
+			std::cout << "Error loading scene: cannot open " << sFileName << "\n";
+			return false;
+		}
+		const char* pFile = pMapped ? pMapped : (const char*)stdBytes.data();
+		const size_t iSize = pMapped ? iMappedSize : stdBytes.size();
+		//pieces of about equal size that end behind a line end
+		std::vector<Piece> stdPieces(iThreads);
+		size_t iFrom = 0;
+		for (uint32_t t = 0; t < iThreads; t++)
+		{
+			size_t iTo = t + 1 == iThreads ? iSize : std::max(iFrom, iSize * (t + 1) / iThreads);
+			while (iTo < iSize && iTo > 0 && pFile[iTo - 1] != '\n') iTo++;
+			stdPieces[t].Begin = pFile + iFrom; stdPieces[t].End = pFile + iTo;
+			iFrom = iTo;
+		}
+		RunThreads(iThreads, [&](uint32_t t) { ParsePiece(stdPieces[t]); });
+
+		//what came before every piece
+		std::vector<uint64_t> stdV(iThreads + 1, 0), stdVT(iThreads + 1, 0), stdVN(iThreads + 1, 0), stdF(iThreads + 1, 0), stdL(iThreads + 1, 0);
+		for (uint32_t t = 0; t < iThreads; t++)
+		{
+			stdV[t + 1] = stdV[t] + stdPieces[t].Positions.size() / 3; stdVT[t + 1] = stdVT[t] + stdPieces[t].Texcoords.size() / 2;
+			stdVN[t + 1] = stdVN[t] + stdPieces[t].Normals.size() / 3; stdF[t + 1] = stdF[t] + stdPieces[t].Faces.size();
+			stdL[t + 1] = stdL[t] + stdPieces[t].Lines;
+		}
+		BigVector<float> stdPositions(stdV[iThreads] * 3), stdTexcoords(stdVT[iThreads] * 2), stdNormals(stdVN[iThreads] * 3);
+		RunThreads(iThreads, [&](uint32_t t) {
+			const Piece& c = stdPieces[t];
+			if (!c.Positions.empty()) std::memcpy(&stdPositions[stdV[t] * 3], c.Positions.data(), c.Positions.size() * sizeof(float));
+			if (!c.Texcoords.empty()) std::memcpy(&stdTexcoords[stdVT[t] * 2], c.Texcoords.data(), c.Texcoords.size() * sizeof(float));
+			if (!c.Normals.empty()) std::memcpy(&stdNormals[stdVN[t] * 3], c.Normals.data(), c.Normals.size() * sizeof(float));
+		});
+
+		//vertices face by face; a piece remembers its first bad face: (line, 0 = bad index, 1 = not a triangle)
+		const uint64_t iNumFaces = stdF[iThreads];
+		rtParsed.Vertices.assign(iNumFaces * 3, Vertex{});
+		std::vector<std::pair<uint64_t, int>> stdFirstError(iThreads, { ~0ull, 0 });
+		std::vector<uint8_t> stdNeedNormals(iThreads, 0);
+		RunThreads(iThreads, [&](uint32_t t) {
+			const Piece& c = stdPieces[t];
+			size_t iExtra = 0;
+			for (size_t k = 0; k < c.Faces.size(); k++)
+			{
+				const FaceRecord& f = c.Faces[k];
+				const int iNumV = (int)(stdV[t] + f.NumV), iNumVT = (int)(stdVT[t] + f.NumVT), iNumVN = (int)(stdVN[t] + f.NumVN);
+				Vertex* rtCorner = &rtParsed.Vertices[(stdF[t] + k) * 3];
+				int iError = -1;
+				for (uint32_t j = 0; j < f.NumCorners && iError < 0; j++)
+				{
+					RawCorner rtRaw;
+					if (j < 3) rtRaw = f.Corners[j];
+					else { while (c.Extra[iExtra].first != k) iExtra++; rtRaw = c.Extra[iExtra].second; }
+					int iIdx[3];
+					if (!FixCorner(rtRaw, iNumV, iNumVT, iNumVN, iIdx) || iIdx[0] < 0 || iIdx[0] >= iNumV) { iError = 0; break; }
+					if (j == 3) { iError = 1; break; }
+					Vertex& v = rtCorner[j];
+					v.Position = { stdPositions[3 * (size_t)iIdx[0]], stdPositions[3 * (size_t)iIdx[0] + 1], stdPositions[3 * (size_t)iIdx[0] + 2] };
+					if (iIdx[1] >= 0 && iIdx[1] < iNumVT) v.UV = { stdTexcoords[2 * (size_t)iIdx[1]], stdTexcoords[2 * (size_t)iIdx[1] + 1] };
+					if (iIdx[2] >= 0 && iIdx[2] < iNumVN) v.Normal = { stdNormals[3 * (size_t)iIdx[2]], stdNormals[3 * (size_t)iIdx[2] + 1], stdNormals[3 * (size_t)iIdx[2] + 2] };
+					else stdNeedNormals[t] = 1;
+				}
+				if (iError < 0 && f.NumCorners != 3) iError = 1;
+				if (iError >= 0) { stdFirstError[t] = { stdL[t] + f.Line, iError }; return; }
+			}
+		});
+		for (uint32_t t = 0; t < iThreads; t++)
+		{
+			if (stdFirstError[t].first == ~0ull) continue;
+			if (stdFirstError[t].second == 0) std::cout << "Error loading scene: bad face index in line " << stdFirstError[t].first << "\n";
+			else std::cout << "Error loading scene: only triangles are supported (line " << stdFirstError[t].first << ")\n";
+			return false;
+		}
+		for (uint32_t t = 0; t < iThreads; t++) rtParsed.CalculateNormals = rtParsed.CalculateNormals || stdNeedNormals[t] != 0;
+
+		//events in file order: the material every face is written with
+		std::unordered_map<std::string, int> stdMaterialMap;
+		int iCurrentMaterial = -1;
+		std::vector<std::vector<int>> stdMaterialAfter(iThreads);		//[piece][e] = material after e events of the piece
+		for (uint32_t t = 0; t < iThreads; t++)
+		{
+			stdMaterialAfter[t].push_back(iCurrentMaterial);
+			for (const PieceEvent& e : stdPieces[t].Events)
+			{
+				if (e.Library)
+				{
+					std::stringstream stdNames(e.Text);
+					std::string sName;
+					while (stdNames >> sName) { if (LoadMTL(sDirectory + sName, rtParsed.Materials, stdMaterialMap)) break; }
+				}
+				else
+				{
+					auto stdFound = stdMaterialMap.find(e.Text);
+					iCurrentMaterial = stdFound == stdMaterialMap.end() ? -1 : stdFound->second;
+				}
+				stdMaterialAfter[t].push_back(iCurrentMaterial);
+			}
+		}
+		RunThreads(iThreads, [&](uint32_t t) {
+			const Piece& c = stdPieces[t];
+			for (size_t k = 0; k < c.Faces.size(); k++)
+			{
+				const uint32_t iMaterial = (uint32_t)stdMaterialAfter[t][c.Faces[k].Event];
+				Vertex* rtCorner = &rtParsed.Vertices[(stdF[t] + k) * 3];
+				rtCorner[0].MaterialID = rtCorner[1].MaterialID = rtCorner[2].MaterialID = iMaterial;
+			}
+		});
+		return true;
+	}
+
+	MeshInfo LoadMeshFromFile(const std::string& sFileName, bool bDeduplicate, uint32_t iThreads)
+	{
+		//the material library is looked up next to the OBJ file
+		std::string sDirectory;
+		{
+			size_t iSlash = sFileName.find_last_of("/\\");
+			if (iSlash != std::string::npos) sDirectory = sFileName.substr(0, iSlash + 1);
+		}
+		if (iThreads == 0)
+		{
+			//small files are not worth the threads; the share of a GPU box's cores that one GPU gets is 16
+			std::ifstream stdProbe(sFileName, std::ios::binary | std::ios::ate);
+			const std::streamoff iBytes = stdProbe ? (std::streamoff)stdProbe.tellg() : 0;
+			const uint32_t iCores = std::thread::hardware_concurrency();
+			iThreads = iBytes < (1 << 20) ? 1u : std::min(16u, std::max(1u, iCores));
+		}
+		ParsedOBJ rtParsed;
+		const bool bParsed = iThreads == 1 ? ParseOBJSerial(sFileName, sDirectory, rtParsed)
+		                                    : ParseOBJParallel(sFileName, sDirectory, std::min(iThreads, 256u), rtParsed);
+		if (!bParsed) return MeshInfo{};
+		return FinishMesh(sFileName, rtParsed, bDeduplicate, iThreads);
 	}
 
 

@@ -79,7 +79,9 @@ namespace RT::GraphicsAPI
 	//bDeduplicate: equal vertices (position, UV, normal and material, compared as the reference's VerticesAreEqual does,
 	//src/RaytracerMesh.cpp:157-169 of the reference) are stored once and shared through the index buffer - the loop the
 	//reference has commented out as too slow (src/RaytracerMesh.cpp:249-275), done with a hash table. Default: off, as there.
-	MeshInfo LoadMeshFromFile(const std::string& sFileName, bool bDeduplicate = false);
+	//iThreads: 1 = the file is parsed line by line as the reference's parser does; more = by that many threads (same
+	//MeshInfo, bit for bit); 0 = chosen by the size of the file and the cores there are
+	MeshInfo LoadMeshFromFile(const std::string& sFileName, bool bDeduplicate = false, uint32_t iThreads = 0);
 	//frees the host arrays of a MeshInfo that was not handed to RaytracerMesh::Initialize
 	void ReleaseMeshInfo(MeshInfo& rtMesh);
 

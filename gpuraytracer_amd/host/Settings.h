@@ -64,6 +64,7 @@ namespace RT
 		bool PreviewEveryBounce = true;     //the reference shows the running image after every Render() call (one bounce); false = the
 		                                    //final-image kernel runs only when a sample cycle is complete (same accumulated image)
 		bool DeduplicateVertices = false;   //LoadMeshFromFile merges equal vertices (the loop the reference has switched off)
+		uint32_t LoaderThreads = 0;         //threads LoadMeshFromFile parses the OBJ file with (1 = line by line; 0 = by file size and cores)
 		uint32_t DeviceRank = 0;            //multi-GPU: this pipeline renders the image rows DeviceRank, DeviceRank + DeviceCount, ...
 		uint32_t DeviceCount = 1;           //(one pipeline per GPU, same scene and seeds on each; RaytracerPipeline::GatherOutput assembles the image)
 		uint32_t SeedRayGen = 0;            //std::mt19937 seeds of the two host generators; 0 = std::random_device

@@ -39,6 +39,7 @@ def load():
         "rth_parse_real": (C.c_float, [C.c_char_p]),
         "rth_load_mesh": (_P, [C.c_char_p]),
         "rth_load_mesh_dedup": (_P, [C.c_char_p]),
+        "rth_load_mesh_threads": (_P, [C.c_char_p, C.c_int, C.c_uint32]),
         "rth_synthetic_scene": (_P, [C.c_uint32, C.c_uint32]),
         "rth_mesh_index_count": (C.c_uint64, [_P]), "rth_mesh_vertex_count": (C.c_uint64, [_P]),
         "rth_mesh_material_count": (C.c_uint64, [_P]), "rth_mesh_texture_count": (C.c_uint64, [_P]),
@@ -104,11 +105,12 @@ def _mesh_to_scene(lib, h, texture_prefix="", camera=None, name=""):
                 camera=camera, name=name)
 
 
-def load_scene(obj_path, texture_prefix="", camera=None, dedup=False):
+def load_scene(obj_path, texture_prefix="", camera=None, dedup=False, threads=0):
     """LoadMeshFromFile + TextureAtlas packing through the C++ host; returns a scene dict. dedup: equal vertices are
-    merged (LoadMeshFromFile's bDeduplicate)."""
+    merged (LoadMeshFromFile's bDeduplicate); threads: 1 = the file is parsed line by line, more = by that many threads,
+    0 = chosen by the file's size."""
     lib = load()
-    h = (lib.rth_load_mesh_dedup if dedup else lib.rth_load_mesh)(obj_path.encode())
+    h = lib.rth_load_mesh_threads(obj_path.encode(), int(dedup), int(threads))
     if not h:
         raise RuntimeError("LoadMeshFromFile failed for %s" % obj_path)
     try:

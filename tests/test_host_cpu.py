@@ -384,3 +384,110 @@ def test_counter_file_of_the_round_travels_with_the_tree():
     if os.path.exists(ignore):
         lines = [l.strip() for l in open(ignore) if l.strip()]
         assert not any(l.strip("./").startswith("profiles") for l in lines)
+
+
+# ------------------------------------------------------------------ the OBJ file parsed by several threads ----
+
+def _write_mixed_obj(path, faces=400, seed=3, crlf=False, final_newline=True):
+    """An OBJ file that uses what the parser knows, in an order that makes "the counts so far" matter: v / vt / vn lines
+    between the faces, 1-based and relative indices, all four corner forms, comments, blank lines, trailing blanks,
+    materials switched (known, unknown, before their library is named), a second library half way."""
+    rng = np.random.RandomState(seed)
+    d = os.path.dirname(path)
+    with open(os.path.join(d, "first.mtl"), "w") as f:
+        f.write("newmtl red\nKd 0.8 0.1 0.1\nKe 0.2 0.2 0.2\nnewmtl blue\nKd 0.1 0.1 0.9\nNs 50\n")
+    with open(os.path.join(d, "second.mtl"), "w") as f:
+        f.write("newmtl green\nKd 0.1 0.7 0.1\nPr 0.4\nPm 0.6\n")
+    lines = ["# mixed test file", "usemtl red", "mtllib missing.mtl first.mtl", ""]
+    nv = nvt = nvn = 0
+    for k in range(faces):
+        for _ in range(3):
+            lines.append("v %.6f %.6f %.6f" % tuple(rng.uniform(-5, 5, 3)) + (" " if k % 7 == 0 else ""))
+            nv += 1
+        if k % 3 != 2:
+            for _ in range(3):
+                lines.append("vt %.5f %.5f" % tuple(rng.uniform(0, 1, 2)))
+                nvt += 1
+        if k % 4 != 3:
+            for _ in range(2):
+                n = rng.normal(size=3)
+                lines.append("vn %.6f %.6f %.6f" % tuple(n / np.linalg.norm(n)))
+                nvn += 1
+        if k % 11 == 0:
+            lines.append("usemtl %s" % ["red", "blue", "nothing", "green"][(k // 11) % 4])
+        if k == faces // 2:
+            lines.append("mtllib second.mtl")
+        if k % 13 == 5:
+            lines += ["", "   # a comment", "g group%d" % k, "s off"]
+        form = k % 4
+        corners = []
+        for c in range(3):
+            v = -(3 - c) if k % 2 else nv - 2 + c                               # relative / 1-based
+            vt = (-(c + 1) if k % 5 == 0 else max(nvt - c, 1)) if nvt else 1
+            vn = (-1 if k % 6 == 0 else max(nvn - (c % 2), 1)) if nvn else 1
+            if k % 17 == 3:
+                vt = nvt + 50                                                    # beyond the counts so far: left at zero
+            corners.append(["%d" % v, "%d/%d" % (v, vt), "%d//%d" % (v, vn), "%d/%d/%d" % (v, vt, vn)][form])
+        lines.append("f " + "  ".join(corners) + ("\t " if k % 9 == 0 else ""))
+    text = ("\r\n" if crlf else "\n").join(lines) + (("\r\n" if crlf else "\n") if final_newline else "")
+    with open(path, "w", newline="") as f:
+        f.write(text)
+
+
+def _same_scene(a, b):
+    for k in ("vertices", "indices", "materials", "texture_ids", "scene_min", "scene_max"):
+        assert a[k].tobytes() == b[k].tobytes(), k
+    assert a["texture_names"] == b["texture_names"]
+
+
+@pytest.mark.parametrize("crlf,final_newline", [(False, True), (True, True), (False, False)])
+def test_obj_parsed_by_several_threads_gives_the_same_mesh(tmp_path, crlf, final_newline):
+    from gpuraytracer_amd import host_py
+    path = str(tmp_path / "mixed.obj")
+    _write_mixed_obj(path, crlf=crlf, final_newline=final_newline)
+    for dedup in (False, True):
+        want = host_py.load_scene(path, dedup=dedup, threads=1)
+        assert len(want["indices"]) == 1200 and want["vertices"]["material_id"].max() == 0xFFFFFFFF
+        assert len(set(want["vertices"]["material_id"].tolist())) == 4          # red, blue, green and "none"
+        for threads in (2, 3, 5, 16, 61):
+            _same_scene(host_py.load_scene(path, dedup=dedup, threads=threads), want)
+
+
+@needs_reference_assets
+@pytest.mark.parametrize("name", ["testobject4_2", "testobject5_1", "testscene2"])
+def test_reference_assets_parsed_by_several_threads(name):
+    from gpuraytracer_amd import host_py
+    cwd = os.getcwd()
+    os.chdir("/root/reference")
+    try:
+        want = host_py.load_scene("assets/%s.obj" % name, threads=1)
+        for threads in (2, 7):
+            _same_scene(host_py.load_scene("assets/%s.obj" % name, threads=threads), want)
+    finally:
+        os.chdir(cwd)
+
+
+def test_parser_threads_report_the_first_error_as_the_serial_parser_does(tmp_path, capfd):
+    """Bad files: the message (kind of error and line) of the threaded parser is the line-by-line parser's."""
+    from gpuraytracer_amd import host_py
+    good = ["v 0 0 0", "v 1 0 0", "v 0 1 0", "f 1 2 3"] * 40
+    cases = {
+        "forward": good[:80] + ["f 1 2 500"] + good[80:],                                  # an index beyond the counts so far
+        "zero": good[:120] + ["f 0 1 2"] + good[120:],
+        "quad": good[:60] + ["f 1 2 3 4"] + good[60:] + ["f 1 2 9999"],                     # two errors: the first counts
+        "quad_bad_fourth": good[:100] + ["f 1 2 3 0"] + good[100:],                         # fourth corner: its index is looked at first
+        "two_corners": good + ["f 1 2"],
+        "empty_slot": good[:30] + ["f 1/ 2/ 3/"] + good[30:],
+    }
+    for name, lines in cases.items():
+        path = str(tmp_path / (name + ".obj"))
+        with open(path, "w") as f:
+            f.write("\n".join(lines) + "\n")
+        messages = []
+        for threads in (1, 2, 4, 9):
+            capfd.readouterr()
+            with pytest.raises(RuntimeError):
+                host_py.load_scene(path, threads=threads)
+            messages.append(capfd.readouterr().out.strip())
+        assert messages[0].startswith("Error loading scene:") and "line" in messages[0], (name, messages[0])
+        assert all(m == messages[0] for m in messages), (name, messages)
