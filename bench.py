@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--no-reference-walk", action="store_true",
                     help="skip the two extra frames traced by the walk in the reference's order (reported beside `value`)")
     ap.add_argument("--dynamic", action="store_true", help="move the triangles on the device before every rebuild (always on for c5)")
+    ap.add_argument("--refit", action="store_true",
+                    help="moving scenes: build once, then refit (rt_accel_refit) instead of the per-frame rebuild the workloads are defined with")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: rays per pixel grow with the GPU count; strong: the frame is fixed")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -173,7 +175,8 @@ def main():
         band = torch.zeros((num_rows, width, 4), dtype=torch.float32, device="cuda")
         pipe = Pipeline(dev, scene, width, height, iv, ip, rpp=rpp, depth=depth, use_bvh=True, use_accel=True,
                         raygen_seeds=lambda: next(rs), trace_seeds=lambda: next(ts), first_row=first_row, num_rows=num_rows,
-                        row_stride=row_stride, dynamic=args.dynamic or args.workload == "c5", rebuild_every_cycle=True, output_ptr=band.data_ptr())
+                        row_stride=row_stride, dynamic=args.dynamic or args.workload == "c5", rebuild_every_cycle=True, output_ptr=band.data_ptr(),
+                        refit=args.refit)
 
         build_events, trace_events = [], []
         raw_build, raw_trace = pipe.build, pipe.trace
@@ -301,7 +304,7 @@ def main():
     achieved = bytes_per_launch / avg_trace_s / 1e9
     avg_build_ms = float(np.mean(build_ms))
 
-    plain = not (args.triangles or args.width or args.height or args.band or args.dynamic) and args.scaling == "weak" and world == 1
+    plain = not (args.triangles or args.width or args.height or args.band or args.dynamic or args.refit) and args.scaling == "weak" and world == 1
     kernel_symbol = {"spatial": "k_traverse_spatial", "quad": "k_traverse_quad", "wave": "k_traverse", "simple": "k_trace"}.get(kernel_name, kernel_name)
     counters, counter_file = load_pmc(args.workload, kernel_symbol) if plain else (None, None)
     fr = counter_fractions(counters, avg_trace_s) if counters else {}
@@ -340,6 +343,7 @@ def main():
                    "custom: synthetic %d-triangle scene, %dx%d, %d ray/pixel, %d bounces, LBVH rebuilt every frame" % (ntri, width, height, rpp, depth),
                    "triangles": ntri, "width": width, "height": height, "rays_per_pixel": rpp, "bounces": depth,
                    "final_image": "once per frame (after the last bounce)",
+                   "build": "refit after the first frame (not the workload as defined)" if args.refit else "rebuilt every frame",
                    "parallelism": "image rows dealt to %d GPU(s) in turn, replicated scene + per-GPU rebuild, gather to rank 0" % world},
         "lbvh_build_ms": round(avg_build_ms, 4),
         "roofline": roofline,

@@ -141,6 +141,7 @@ SIGNATURES = {
     "rt_scene_bounds": (C.c_int, [_P, _U32, _P, _P, _P]),
     "rt_scene_bounds_static": (C.c_int, [_P, _U32, _P, _P, _P]),
     "rt_accel_pack_bounds": (C.c_int, [_P, _U32, _P, _P, _P]),
+    "rt_accel_refit": (C.c_int, [_P, _P]),
     "rt_accel_build_device_bounds": (C.c_int, [_P, _P, _P, _P]),
     "rt_synthetic_animate": (C.c_int, [_P, _U32, _U32, _P, _P]),
     "rt_rows_for_rank": (C.c_int, [_U32, _U32, _U32, C.POINTER(ImageRows)]),

@@ -376,6 +376,16 @@ __global__ __launch_bounds__(256) void k_cell_starts(uint32_t n, const uint2* __
         for (uint32_t k = c + 1u; k <= (1u << T); k++) start[k] = n;
 }
 
+// rt_accel_refit: the sorted (code, 3 * triangle) pairs of the last build, as far as k_leaves reads them (the triangle),
+// from the leaf records that build wrote
+__global__ __launch_bounds__(256) void k_order_from_leaves(uint32_t n, const float4* __restrict__ sorted_tris, uint2* __restrict__ keys) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (2u * g >= n) return;
+    const float4 l4 = sorted_tris[RT_LEAF_STRIDE * (size_t)g + 4u];
+    keys[2u * g] = make_uint2(0u, __float_as_uint(l4.z));
+    if (2u * g + 1u < n) keys[2u * g + 1u] = make_uint2(0u, __float_as_uint(l4.w));
+}
+
 __global__ __launch_bounds__(256) void k_expand_keys(uint32_t n, const uint2* __restrict__ keys, uint4* __restrict__ morton) {
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t < n) { uint2 k = keys[t]; morton[t] = make_uint4(k.x, k.y, 0u, 0u); }
@@ -1247,6 +1257,8 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
     a->cells = nullptr;
     a->pairs_valid = a->sp_pairs_valid = false;
     a->sp_built = false;
+    a->built_prims = 0;
+    a->sp_sorted = nullptr;
     a->want_spatial = true;
     a->cell_bits_cap = RT_CELL_BITS_MAX;
     const size_t tri_bytes = (size_t)max_primitives * 48u, key_bytes = (size_t)max_primitives * 8u;
@@ -1415,6 +1427,46 @@ int rt_accel_build_device_bounds(rt_accel* a, const rt_buffer* bounds, rt_buffer
     return accel_build(a, zero, zero, (const float*)bounds->ptr, bvh, morton_codes);
 }
 
+int rt_accel_refit(rt_accel* a, rt_buffer* bvh) {
+    if (!a || !bvh) return RT_ERR_INVALID_ARGUMENT;
+    const uint32_t n = a->num_prims;
+    if (!a->built_prims || a->built_prims != n) return RT_ERR_INVALID_ARGUMENT;       // nothing of this size to refit
+    rt_levels lv;
+    if (!rt_make_levels(n, &lv)) return RT_ERR_TOO_FEW_PRIMITIVES;
+    if (bvh->bytes < (size_t)rt_bvh_node_count(n) * 32u) return RT_ERR_BUFFER_TOO_SMALL;
+    rt_device* dev = a->dev;
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+    hipStream_t s = dev->stream;
+    dev->missed_valid = false;
+    const bool own = a->sp_built && a->sp_sorted != nullptr;
+    // the order of the last build, read back from its leaf records into the key buffer that is free
+    uint2* order = (own && a->sp_sorted == a->keys_b) ? a->keys_a : a->keys_b;
+    const uint32_t leaves = lv.n[0];
+    const SceneBounds none{};           // (scene bounds only enter the keys, which a refit does not make)
+    hipLaunchKernelGGL(k_order_from_leaves, dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, (const float4*)a->sorted_tris, order);
+    a->pairs_valid = a->sp_pairs_valid = false;
+    hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)order,
+                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr,
+                       a->quads, (const uint32_t*)nullptr, 0u, (const float4*)nullptr, 0.0f, (uint2*)nullptr, none, (const float*)nullptr,
+                       (const uint32_t*)nullptr);
+    for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
+        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, a->quads);
+    if (!own) return rt_launch_status();
+    // the library's own hierarchy: same slots, same pairs of triangles, corners from the leaf records written above
+    const uint32_t slots = rt_spatial_slots(n);
+    uint32_t slots_log2 = 0u;
+    while ((1u << slots_log2) < slots) slots_log2++;
+    const rt_levels& sl = a->sp_lv;
+    hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(slots, 256u)), dim3(256), 0, s, 2u * slots, sl, (const uint32_t*)a->sp_sorted,
+                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads,
+                       (const uint32_t*)a->cells, slots_log2, (const float4*)a->sorted_tris, dev->walk_sliver_pad, (uint2*)nullptr, none,
+                       (const float*)nullptr, (const uint32_t*)nullptr);
+    for (uint32_t k0 = 8u; k0 + 1u < sl.count; k0 += 8u)
+        hipLaunchKernelGGL(k_upsweep, dim3(div_up(sl.n[k0], 256u)), dim3(256), 0, s, k0, sl, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads);
+    return rt_launch_status();
+}
+
 namespace {
 
 int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, const float* dbounds, rt_buffer* bvh,
@@ -1463,11 +1515,14 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
         hipLaunchKernelGGL(k_expand_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, n, src, (uint4*)morton_codes->ptr);
 
     a->sp_built = own;
+    a->built_prims = n;
+    a->sp_sorted = nullptr;
     if (!own) return rt_launch_status();
     // (key, place in the reference's order) of every triangle, written by the leaf kernel above, sorted by key
     uint2* sp_src = nullptr;
     rc = rt_sort_pairs(dev, other, src, n, 4u, &sp_src);
     if (rc) return rc;
+    a->sp_sorted = sp_src;
     // leaf slots by Morton cell where the cells fit (k_cell_choose), then leaves and levels over all the slots
     const uint32_t slots = rt_spatial_slots(n);
     uint32_t slots_log2 = 0u;

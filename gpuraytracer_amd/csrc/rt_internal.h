@@ -209,6 +209,8 @@ struct rt_accel {
     bool want_spatial;         // rt_accel_set_second_hierarchy: builds make the library's own hierarchy
     uint32_t cell_bits_cap;    // ... with leaf slots aligned to Morton cells of at most this many bits
     bool sp_built;             // the last build made it
+    uint32_t built_prims;      // triangles of the last build (0: none yet) - what rt_accel_refit may refit
+    uint2* sp_sorted;          // keys_a or keys_b: the own hierarchy's sorted (key, place) pairs of the last build
     rt_levels sp_lv;           // shape of that hierarchy at the last build: rt_spatial_slots(num_prims) leaves, all levels full
 };
 // rt_accel::cells, in uint32 (everything before RT_CELLS_START is cleared by every build): [0..7] layout {cell bits T, largest cell at T = 21, 18, ... 3}; then the triangles per cell

@@ -26,6 +26,7 @@ struct rth_settings
 	int32_t reference_order_walk;
 	int32_t drop_missed_rays;
 	int32_t no_previews;
+	int32_t refit;
 	uint32_t device_rank, device_count;
 };
 
@@ -130,6 +131,7 @@ static Settings ToSettings(const rth_settings* s)
 	r.ReferenceOrderWalk = s->reference_order_walk != 0;
 	r.DropMissedRays = s->drop_missed_rays != 0;
 	r.PreviewEveryBounce = s->no_previews == 0;
+	r.RefitBVH = s->refit != 0;
 	r.DeviceRank = s->device_rank;
 	r.DeviceCount = s->device_count ? s->device_count : 1;
 	return r;

@@ -4,7 +4,7 @@
 //
 //   rt_headless [--scene file.obj | --synthetic N] [--width W] [--height H] [--rpp R] [--depth D]
 //               [--cycles C] [--no-bvh] [--per-shader-build] [--rebuild] [--camera px py pz fx fy fz]
-//               [--seed S] [--gpu G] [--out image.ppm|image.png] [--pfm image.pfm] [--dynamic] [--reference-walk]
+//               [--seed S] [--gpu G] [--out image.ppm|image.png] [--pfm image.pfm] [--dynamic] [--refit] [--reference-walk]
 //               [--resume state.bin] [--save-state state.bin] [--dedup] [--loader-threads T] [--drop-missed-rays] [--no-previews]
 //               [--ranks N]
 //
@@ -159,6 +159,7 @@ int main(int argc, char** argv)
 		else if (!std::strcmp(argv[i], "--pfm")) rtOptions.sPFM = Next();
 		else if (!std::strcmp(argv[i], "--dynamic")) rtSettings.DynamicScene = true;
 		else if (!std::strcmp(argv[i], "--reference-walk")) rtSettings.ReferenceOrderWalk = true;
+		else if (!std::strcmp(argv[i], "--refit")) rtSettings.RefitBVH = true;
 		else if (!std::strcmp(argv[i], "--dedup")) rtSettings.DeduplicateVertices = true;
 		else if (!std::strcmp(argv[i], "--loader-threads")) rtSettings.LoaderThreads = (uint32_t)std::atoi(Next());
 		else if (!std::strcmp(argv[i], "--drop-missed-rays")) rtSettings.DropMissedRays = true;

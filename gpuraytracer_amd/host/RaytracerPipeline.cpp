@@ -332,6 +332,16 @@ namespace RT::GraphicsAPI
 		return rt_accel_build_device_bounds(m_rtAccel, rtBounds, m_rtBVHBuffer, rtMortonCodes) == RT_OK;
 	}
 
+	bool BuildBVH::Refit(RaytracerMesh* rtMesh)
+	{
+		if (!m_rtAccel) return false;
+		const rt_buffer* rtIndices = nullptr;
+		const rt_buffer* rtVertices = nullptr;
+		rtMesh->Bind(&rtIndices, &rtVertices);
+		if (rt_accel_pack(m_rtAccel, m_iNumPrimitives, rtIndices, rtVertices) != RT_OK) return false;
+		return rt_accel_refit(m_rtAccel, m_rtBVHBuffer) == RT_OK;
+	}
+
 	bool BuildBVH::BuildFused(RaytracerMesh* rtMesh, AABB rtSceneAABB, rt_buffer* rtMortonCodes)
 	{
 		if (!m_rtAccel)
@@ -608,7 +618,12 @@ namespace RT::GraphicsAPI
 			if (m_bBuildBVH || (m_rtSettings.RebuildBVHEveryCycle && m_iIteration == 0))
 			{
 				if (m_rtSettings.DynamicScene && !MoveScene()) return false;
-				if (m_rtSettings.DynamicScene && m_rtSettings.FusedBuild)
+				if (m_rtSettings.DynamicScene && m_rtSettings.FusedBuild && m_rtSettings.RefitBVH && !m_bBuildBVH)
+				{
+					//every build after the first keeps the first one's order
+					if (!(m_rtBuildBVH->Refit(m_rtTraceRays->GetMesh()))) return false;
+				}
+				else if (m_rtSettings.DynamicScene && m_rtSettings.FusedBuild)
 				{
 					if (!(m_rtBuildBVH->BuildFusedMoved(m_rtTraceRays->GetMesh(), m_rtBoundsBuffer, m_rtSortPrimitives->GetMortonCodes()))) return false;
 				}

@@ -122,6 +122,9 @@ namespace RT::GraphicsAPI
 		//the same for a mesh that has moved on the device: gathers the triangles again, leaves their centroid bounds
 		//(8 floats) in rtBounds and builds with them, without a round trip to the host
 		bool BuildFusedMoved(RaytracerMesh* rtMesh, rt_buffer* rtBounds, rt_buffer* rtMortonCodes);
+		//leaves and levels again over the moved vertices in the sorted order of the last fused build (rt_accel_refit);
+		//false if there is no such build yet
+		bool Refit(RaytracerMesh* rtMesh);
 
 		//whether the fused builds also make the library's own hierarchy (the default traversal walks it); off for a
 		//pipeline that traces in the reference's order, which never reads it

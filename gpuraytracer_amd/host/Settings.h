@@ -57,6 +57,8 @@ namespace RT
 		bool FusedBuild = true;             //one fused LBVH build instead of one launch per reference dispatch
 		bool DynamicScene = false;          //the synthetic moving workload: before every cycle the triangles are moved on the
 		                                    //device (rt_synthetic_animate), the scene bounds reduced there and the tree rebuilt
+		bool RefitBVH = false;              //DynamicScene with FusedBuild: the hierarchy is built once and then refitted - leaves and levels
+		                                    //over the first build's sorted order (rt_accel_refit) - instead of rebuilt every cycle
 		bool ReferenceOrderWalk = false;    //trace by the walk of the reference's hierarchy in the reference's order
 		                                    //(RT_TRACE_KERNEL_QUAD) instead of the default on the library's own hierarchy
 		bool DropMissedRays = false;        //leave rays that have missed out of the later bounces of their sample cycle instead of

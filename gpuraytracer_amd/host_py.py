@@ -17,7 +17,7 @@ class HostSettings(C.Structure):
                 ("near_z", C.c_float), ("far_z", C.c_float), ("cam_position", C.c_float * 3), ("cam_focus", C.c_float * 3),
                 ("cam_up", C.c_float * 3), ("rebuild_every_cycle", C.c_int32), ("fused_build", C.c_int32),
                 ("seed_raygen", C.c_uint32), ("seed_trace", C.c_uint32), ("dynamic_scene", C.c_int32),
-                ("reference_order_walk", C.c_int32), ("drop_missed_rays", C.c_int32), ("no_previews", C.c_int32), ("device_rank", C.c_uint32),
+                ("reference_order_walk", C.c_int32), ("drop_missed_rays", C.c_int32), ("no_previews", C.c_int32), ("refit", C.c_int32), ("device_rank", C.c_uint32),
                 ("device_count", C.c_uint32)]
 
 
@@ -159,7 +159,7 @@ class HostPipeline:
 
     def __init__(self, dev, mesh_source, width, height, camera, rpp=1, depth=3, aa=1.5, dof=0.0, use_bvh=True, fused_build=True,
                  rebuild_every_cycle=False, seed_raygen=1, seed_trace=2, dynamic=False, reference_order_walk=False,
-                 drop_missed_rays=False, device_rank=0, device_count=1, previews=True):
+                 drop_missed_rays=False, device_rank=0, device_count=1, previews=True, refit=False):
         self.lib = load()
         self.dev = dev
         self.width, self.height = width, height
@@ -184,6 +184,7 @@ class HostPipeline:
         s.reference_order_walk = int(reference_order_walk)
         s.drop_missed_rays = int(drop_missed_rays)
         s.no_previews = int(not previews)
+        s.refit = int(refit)
         s.device_rank, s.device_count = int(device_rank), int(device_count)
         self.handle = self.lib.rth_pipeline_create(dev.handle, mesh, C.byref(s))
         if not self.handle:

@@ -18,7 +18,7 @@ from .runtime import Accel, Device
 class Pipeline:
     def __init__(self, dev, scene, width, height, inverse_view, inverse_projection, rpp=1, depth=3, aa=1.5, dof=0.0,
                  use_bvh=True, use_accel=True, raygen_seeds=None, trace_seeds=None, first_row=0, num_rows=None,
-                 row_stride=1, rebuild_every_cycle=False, output_ptr=None, dynamic=False):
+                 row_stride=1, rebuild_every_cycle=False, output_ptr=None, dynamic=False, refit=False):
         self.dev = dev
         self.lib = dev.lib
         self.width, self.height, self.rpp, self.depth = int(width), int(height), int(rpp), int(depth)
@@ -32,6 +32,10 @@ class Pipeline:
         # dynamic: before every rebuild the synthetic animation moves the triangles on the device, and the
         # centroid bounds the Morton codes are scaled by are reduced on the device, too
         self.dynamic = bool(dynamic)
+        # refit: after the first build of a moving scene the sorted order is kept and only leaves and levels are made
+        # again (rt_accel_refit); needs the fused build
+        self.refit = bool(refit)
+        self.builds = 0
         self.frame = 0
         self.raygen_seeds = raygen_seeds    # callable returning 3 uint32 per camera-ray generation
         self.trace_seeds = trace_seeds      # callable returning 3 uint32 per trace dispatch
@@ -99,11 +103,15 @@ class Pipeline:
 
     # ---- LBVH build ----
     def build_fused(self):
-        if self.dynamic:
+        if self.dynamic and self.refit and self.builds > 0:
+            self.accel.pack(self.num_prims, self.indices, self.vertices)
+            self.accel.refit(self.bvh)
+        elif self.dynamic:
             self.accel.pack_bounds(self.num_prims, self.indices, self.vertices, self.bounds)
             self.accel.build_device_bounds(self.bounds, self.bvh)
         else:
             self.accel.build(self.scene_min, self.scene_max, self.bvh)
+        self.builds += 1
 
     def animate(self):
         """Moves the triangles to their places of frame self.frame (synthetic dynamic workload)."""

@@ -121,6 +121,10 @@ class Accel:
         capi.check(self.lib.rt_accel_build_device_bounds(self.handle, bounds.handle, bvh.handle,
                                                          morton.handle if morton else None), "rt_accel_build_device_bounds")
 
+    def refit(self, bvh):
+        """Leaves and levels again over the triangles packed since, in the order of the last build (rt_accel_refit)."""
+        capi.check(self.lib.rt_accel_refit(self.handle, bvh.handle), "rt_accel_refit")
+
     def build(self, scene_min, scene_max, bvh, morton=None):
         mn = (C.c_float * 3)(*[float(x) for x in scene_min])
         mx = (C.c_float * 3)(*[float(x) for x in scene_max])

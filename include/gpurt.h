@@ -272,6 +272,13 @@ int rt_accel_build(rt_accel* accel, const float scene_min[3], const float scene_
 /* rt_accel_build with the scene bounds read from device memory (rt_scene_bounds' layout): a per-frame
  * rebuild of a moving mesh without a round trip to the host. */
 int rt_accel_build_device_bounds(rt_accel* accel, const rt_buffer* bounds, rt_buffer* bvh, rt_buffer* morton_codes);
+/* Refit (no counterpart in the reference, which sorts again on every build): leaves and levels once more over the
+ * vertices packed since (rt_accel_pack / rt_accel_pack_bounds of the same mesh after it has moved), in the sorted order
+ * of the accel's last rt_accel_build - i.e. CS_BVHBuildLeaves and CS_BVHBuild run over the Morton records of that build.
+ * bvh receives the nodes (same count, same links, new boxes); the library's own hierarchy, if the build made one, is
+ * refitted as well. Skips the Morton codes, both sorts and the cell layout; the hierarchy loosens as triangles move
+ * away from where they were sorted, so rebuild now and then. RT_ERR_INVALID_ARGUMENT without a build to refit. */
+int rt_accel_refit(rt_accel* accel, rt_buffer* bvh);
 /* Workload helper (no counterpart in the reference, whose scenes are static): the synthetic dynamic scene.
  * Triangle i of base_vertices (vertices 3i .. 3i + 2, 48-byte rt_vertex) is written to vertices moved as a
  * whole by d = 0.25 * sin(2 pi * frac(frame / 32 + 0.618 * i)) along each axis; the other vertex fields are

@@ -196,7 +196,7 @@ class Pipeline:
             s.cam_up[k] = cam["up"][k]
         s.seed_raygen, s.seed_trace = seed_raygen, seed_trace
         s.true_division = 1 if true_division else 0
-        s.rebuild_every_cycle = 1 if rebuild_every_cycle else 0
+        s.rebuild_every_cycle = int(rebuild_every_cycle)          # True / 1: rebuild per cycle; 2: refit per cycle after the first build
         self.scene = scene  # keeps the arrays alive during create
         atlas = np.ascontiguousarray(scene["atlas"], dtype=np.uint32).reshape(-1, 4)
         self.handle = self.lib.orc_pipeline_create(

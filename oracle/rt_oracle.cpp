@@ -904,8 +904,11 @@ int orc_pipeline_render(orc_pipeline* p) {
     if (p->s.use_bvh) {
         bool rebuild = !p->built || (p->s.rebuild_every_cycle && p->iteration == 0);
         if (rebuild) {
-            orc_sort_primitives(p->scene_min, p->scene_max, p->num_prims, p->indices.data(), p->vertices.data(),
-                                p->morton.data(), p->temp.data(), p->freq.data(), 0);
+            // rebuild_every_cycle = 2: after the first build the sorted order is kept and only CS_BVHBuildLeaves and
+            // CS_BVHBuild run again over the new vertices (a refit; the reference has no such mode)
+            if (!p->built || p->s.rebuild_every_cycle != 2)
+                orc_sort_primitives(p->scene_min, p->scene_max, p->num_prims, p->indices.data(), p->vertices.data(),
+                                    p->morton.data(), p->temp.data(), p->freq.data(), 0);
             if (!orc_build_bvh(p->num_prims, p->indices.data(), p->vertices.data(), p->morton.data(), p->bvh.data()))
                 return 0;
             p->built = true;

@@ -130,7 +130,8 @@ typedef struct {
     float cam_position[3], cam_focus[3], cam_up[3];
     uint32_t seed_raygen, seed_trace;   /* mt19937 seeds (the reference uses random_device) */
     int32_t true_division;
-    int32_t rebuild_every_cycle;        /* 0: build once as the reference does */
+    int32_t rebuild_every_cycle;        /* 0: build once as the reference does; 1: rebuild at every sample cycle; 2: build once, then
+                                           leaves and levels again over the kept order at every sample cycle (refit) */
 } orc_settings;
 
 typedef struct orc_pipeline orc_pipeline;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times the fused LBVH build alone (no tracing): python scripts/build_time.py <triangles> [repeats] [second hierarchy 0|1]"""
+"""Times the fused LBVH build alone (no tracing), and the refit of the same hierarchy:
+python scripts/build_time.py <triangles> [repeats] [second hierarchy 0|1]"""
 import os
 import sys
 
@@ -28,6 +29,15 @@ for _ in range(reps):
     times.append(a.elapsed_ms(b))
 times.sort()
 med = times[len(times) // 2]
+rtimes = []
+for _ in range(reps):
+    a, b = dev.event(), dev.event()
+    a.record()
+    acc.refit(bvh)
+    b.record()
+    rtimes.append(a.elapsed_ms(b))
+rtimes.sort()
 print("%d triangles, %s: build median %.4f ms, min %.4f ms, %.2f TB/s of the 252 B/triangle = %.3f of the HBM peak"
       % (n, "both hierarchies" if second else "the reference's hierarchy alone", med, times[0], 252.0 * n / (med * 1e-3) / 1e12,
          252.0 * n / (med * 1e-3) / 8e12))
+print("    refit (leaves and levels over the kept order) median %.4f ms, min %.4f ms" % (rtimes[len(rtimes) // 2], rtimes[0]))

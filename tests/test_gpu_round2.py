@@ -684,3 +684,76 @@ def test_merged_vertices_render_the_same_image(device, oracle, tmp_path):
     for o in outs[1:]:
         _same(o, outs[0], "merged vertices")
     assert outs[0]["output"][..., :3].max() > 0.0
+
+
+# ------------------------------------------------------------------ refit ----
+
+@pytest.mark.parametrize("kernel", [KERNEL_SPATIAL, KERNEL_QUAD])
+def test_refit_is_leaves_and_levels_over_the_kept_order(device, oracle, kernel):
+    """rt_accel_refit: the moving scene built once, then refitted at every sample cycle. The oracle does the same with the
+    reference's own build steps (CS_BVHBuildLeaves + CS_BVHBuild over the Morton records of the first build and the moved
+    vertices): hierarchy and all buffers stay identical, frame after frame, for the default kernel (whose own hierarchy
+    is refitted too) and the walk in the reference's order."""
+    from gpuraytracer_amd import capi
+    from gpuraytracer_amd.capi import aabb_dtype
+    from gpuraytracer_amd.pipeline import Pipeline
+    from gpuraytracer_amd import scenes
+    sc = scenes.synthetic_scene(6000)
+    w, h, depth, cycles = 80, 45, 3, 4
+    cam = sc["camera"]
+    iv, ip = oracle.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], w / h, cam["near_z"], cam["far_z"])
+    ri, ti = _seeds(oracle, cycles, depth)
+    capi.check(device.lib.rt_device_set_trace_kernel(device.handle, kernel), "rt_device_set_trace_kernel")
+    gp = Pipeline(device, sc, w, h, iv, ip, depth=depth, raygen_seeds=lambda: next(ri), trace_seeds=lambda: next(ti), dynamic=True, refit=True)
+    op = oracle.Pipeline(sc, w, h, depth=depth, seed_raygen=1, seed_trace=2, rebuild_every_cycle=2)
+    try:
+        first = None
+        for frame in range(cycles):
+            op.set_vertices(oracle.synthetic_animate(sc, frame)["vertices"])
+            gp.render(depth)
+            op.render(depth)
+            nodes = gp.bvh.download(aabb_dtype, device.lib.rt_bvh_node_count(gp.num_prims))
+            assert nodes.tobytes() == op.bvh().tobytes(), "hierarchy differs in frame %d" % frame
+            if first is None:
+                first = nodes.copy()
+            else:
+                assert np.array_equal(nodes["link"], first["link"]), "a refit keeps every link"
+                assert nodes.tobytes() != first.tobytes(), "the boxes follow the triangles"
+            assert gp.output_image().view(np.uint32).tobytes() == op.output().view(np.uint32).tobytes(), "image differs in frame %d" % frame
+        assert gp.result_image().view(np.uint32).tobytes() == op.result().view(np.uint32).tobytes()
+        assert gp.rays.download(np.float32, 8 * w * h).tobytes() == op.rays().view(np.float32).tobytes()
+        if kernel == KERNEL_SPATIAL:
+            # Settings::RefitBVH of the C++ host: the same frames
+            from gpuraytracer_amd import host_py
+            hp = host_py.HostPipeline(device, 6000, w, h, cam, depth=depth, seed_raygen=1, seed_trace=2, dynamic=True, refit=True)
+            hp.render(cycles * depth)
+            assert hp.result().view(np.uint32).tobytes() == op.result().view(np.uint32).tobytes()
+            hp.close()
+    finally:
+        device.lib.rt_device_set_trace_kernel(device.handle, KERNEL_SPATIAL)
+        gp.close()
+        op.close()
+
+
+def test_refit_needs_a_build_of_the_same_size(device):
+    from gpuraytracer_amd import capi, scenes
+    from gpuraytracer_amd.runtime import Accel
+    sc = scenes.synthetic_scene(300)
+    n = 300
+    idx, vtx = device.upload(sc["indices"]), device.upload(sc["vertices"])
+    bvh = device.alloc(32 * device.lib.rt_bvh_node_count(n))
+    acc = Accel(device, n)
+    acc.pack(n, idx, vtx)
+    assert device.lib.rt_accel_refit(acc.handle, bvh.handle) == capi.RT_ERR_INVALID_ARGUMENT          # nothing built yet
+    acc.build(sc["scene_min"], sc["scene_max"], bvh)
+    small = device.alloc(64)
+    assert device.lib.rt_accel_refit(acc.handle, small.handle) == capi.RT_ERR_BUFFER_TOO_SMALL
+    built = bvh.download(np.uint8, 32 * device.lib.rt_bvh_node_count(n)).copy()
+    acc.refit(bvh)                                                                                    # same vertices: same hierarchy
+    device.sync()
+    assert bvh.download(np.uint8, 32 * device.lib.rt_bvh_node_count(n)).tobytes() == built.tobytes()
+    acc.pack(200, idx, vtx)
+    assert device.lib.rt_accel_refit(acc.handle, bvh.handle) == capi.RT_ERR_INVALID_ARGUMENT          # another triangle count
+    acc.destroy()
+    for b in (idx, vtx, bvh, small):
+        b.free()
