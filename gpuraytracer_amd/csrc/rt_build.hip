@@ -354,14 +354,28 @@ __global__ __launch_bounds__(1024) void k_cell_choose(uint32_t* __restrict__ cel
             if (!chosen && T <= t_cap && T + 1u <= slots_log2 && s_max[k] <= 2u << (slots_log2 - T)) chosen = T;
         }
         cells[0] = chosen;
+        cells[RT_CELLS_HIST] = 0u;          // the per-cell counts are done with: their table becomes k_cell_starts' list of long gaps
     }
 }
-// first rank of every cell at the chosen T (cells without triangles included), and the total behind the last
+// first rank of every cell at the chosen T (cells without triangles included), and the total behind the last.
+// The lane of a cell's first triangle also writes the cells without triangles before it; a run of kGapInline or more of
+// them goes on a list that k_cell_fill works off with whole workgroups (a scene whose triangles sit in a few of many
+// cells would otherwise have single lanes write thousands of entries each).
+constexpr uint32_t kGapInline = 32u;
+__device__ __forceinline__ void cell_run(uint32_t* __restrict__ cells, uint32_t from, uint32_t to, uint32_t value) {     // start[from .. to] = value
+    uint32_t* start = cells + RT_CELLS_START;
+    if (to - from < kGapInline) {
+        for (uint32_t k = from; k <= to; k++) start[k] = value;
+    } else {
+        uint32_t* list = cells + RT_CELLS_HIST;               // [0] = runs listed, from [4] on (from, to, value) each
+        const uint32_t i = atomicAdd(list, 1u);               // at most 2^RT_CELL_BITS_MAX / kGapInline runs: 3 words each fit the table
+        list[4u + 3u * i] = from; list[5u + 3u * i] = to; list[6u + 3u * i] = value;
+    }
+}
 __global__ __launch_bounds__(256) void k_cell_starts(uint32_t n, const uint2* __restrict__ sorted, uint32_t* __restrict__ cells) {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= n) return;
     const uint32_t T = cells[0], shift = 30u - T;          // codes have 30 bits: T = 0 puts everything into cell 0
-    uint32_t* start = cells + RT_CELLS_START;
     const uint32_t c = sorted[r].x >> shift;
     uint32_t from = 0u;                                     // cells from..c start at r
     bool boundary = true;
@@ -370,10 +384,17 @@ __global__ __launch_bounds__(256) void k_cell_starts(uint32_t n, const uint2* __
         boundary = before != c;
         from = before + 1u;
     }
-    if (boundary)
-        for (uint32_t k = from; k <= c; k++) start[k] = r;
-    if (r == n - 1u)
-        for (uint32_t k = c + 1u; k <= (1u << T); k++) start[k] = n;
+    if (boundary) cell_run(cells, from, c, r);
+    if (r == n - 1u) cell_run(cells, c + 1u, 1u << T, n);
+}
+__global__ __launch_bounds__(256) void k_cell_fill(uint32_t* __restrict__ cells) {
+    const uint32_t* list = cells + RT_CELLS_HIST;
+    uint32_t* start = cells + RT_CELLS_START;
+    const uint32_t runs = list[0];
+    for (uint32_t i = blockIdx.x; i < runs; i += gridDim.x) {
+        const uint32_t from = list[4u + 3u * i], to = list[5u + 3u * i], value = list[6u + 3u * i];
+        for (uint32_t k = from + threadIdx.x; k <= to; k += 256u) start[k] = value;
+    }
 }
 
 // rt_accel_refit: the sorted (code, 3 * triangle) pairs of the last build, as far as k_leaves reads them (the triangle),
@@ -1534,6 +1555,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     hipLaunchKernelGGL(k_cell_sums, dim3((1u << RT_CELL_BITS_MAX) / 256u), dim3(256), 0, s, a->cells);
     hipLaunchKernelGGL(k_cell_choose, dim3(1), dim3(1024), 0, s, a->cells, slots_log2, a->cell_bits_cap);
     hipLaunchKernelGGL(k_cell_starts, dim3(div_up(n, 256u)), dim3(256), 0, s, n, (const uint2*)sp_src, a->cells);
+    hipLaunchKernelGGL(k_cell_fill, dim3(256), dim3(256), 0, s, a->cells);
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(slots, 256u)), dim3(256), 0, s, 2u * slots, sl, (const uint32_t*)sp_src,
                        (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads,
                        (const uint32_t*)a->cells, slots_log2, (const float4*)a->sorted_tris, dev->walk_sliver_pad, (uint2*)nullptr, spb,
