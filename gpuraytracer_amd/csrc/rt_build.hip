@@ -1237,7 +1237,8 @@ int rt_bvh_build_leaves(rt_device* dev, const rt_bvh_info* info, const rt_buffer
     if (rc) return rc;
     rt_levels lv;
     lv.count = 0;
-    dev->missed_valid = false;          // a new hierarchy: rays that missed the old scene may hit this one
+    dev->missed_valid = false;          // a new hierarchy: rays that missed the old scene may hit this one,
+    dev->keys_ready = false;            // and ray keys made for the old trunk's box are not this one's
     hipLaunchKernelGGL((k_leaves<false, false>), dim3(div_up(leaves, 256u)), dim3(256), 0, dev->stream, n, lv,
                        (const uint32_t*)morton_codes->ptr, (const uint32_t*)indices->ptr, (const rt_vertex*)vertices->ptr,
                        (const float4*)nullptr, (float4*)nullptr, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, (float4*)nullptr,
@@ -1460,6 +1461,7 @@ int rt_accel_refit(rt_accel* a, rt_buffer* bvh) {
     if (rc) return rc;
     hipStream_t s = dev->stream;
     dev->missed_valid = false;
+    dev->keys_ready = false;
     const bool own = a->sp_built && a->sp_sorted != nullptr;
     // the order of the last build, read back from its leaf records into the key buffer that is free
     uint2* order = (own && a->sp_sorted == a->keys_b) ? a->keys_a : a->keys_b;
@@ -1501,7 +1503,8 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     int rc = rt_set_device(dev);
     if (rc) return rc;
     hipStream_t s = dev->stream;
-    dev->missed_valid = false;          // a new hierarchy: rays that missed the old scene may hit this one
+    dev->missed_valid = false;          // a new hierarchy: rays that missed the old scene may hit this one,
+    dev->keys_ready = false;            // and ray keys made for the old trunk's box are not this one's
 
     rc = rt_sort_workspace(dev, n);
     if (rc) return rc;

@@ -50,6 +50,7 @@ int rt_device_create(int gpu_index, rt_device** out) {
     d->drop_missed = false;
     d->missed = nullptr;
     d->missed_valid = false;
+    d->keys_ready = false;
     d->missed_rays = nullptr;
     d->missed_count = 0;
     d->listed_valid = false;

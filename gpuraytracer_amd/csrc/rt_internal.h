@@ -40,6 +40,10 @@ struct rt_device {
     int compute_units;         // of this GPU: the persistent kernels launch a multiple of it
     bool drop_missed;          // rt_device_set_drop_missed_rays
     uint8_t* missed;           // [hit_capacity] one mark per ray: it missed in an earlier trace call of the current rays
+    bool keys_ready;           // ray_keys_a holds the keys of the rays the last trace call left behind (made by its shading kernel)
+    const void* keys_rays;     // ... of this ray buffer,
+    const void* keys_accel;    // ... for this accel's own hierarchy (any build of it clears keys_ready),
+    uint32_t keys_count, keys_cost_bits, keys_bits;     // this many rays, with this key layout
     bool missed_valid;         // the marks belong to the rays of the last trace call (false: cleared before the next one)
     const void* missed_rays;   // ... whose ray buffer and ray count these were
     uint32_t missed_count;

@@ -146,7 +146,8 @@ int rt_camera_ray_generation(rt_device* dev, const rt_camera_ray_gen_info* info,
     for (int k = 0; k < 3; k++) p.seed[k] = info->rng_seed[k];
     p.first_row = first_row; p.num_rows = num_rows; p.row_stride = row_stride;
     const dim3 grid(((uint32_t)W + 63u) / 64u, (num_rows + 3u) / 4u), block(64, 4);
-    dev->missed_valid = false;          // new rays: no ray has missed yet (drop-missed-rays mode)
+    dev->missed_valid = false;          // new rays: no ray has missed yet (drop-missed-rays mode),
+    dev->keys_ready = false;            // and the keys the last shading left behind are not theirs
     hipLaunchKernelGGL(k_raygen, grid, block, 0, dev->stream, p, (float4*)rays->ptr, (float4*)old_rays->ptr,
                        (uint32_t*)ray_pixels->ptr);
     return rt_launch_status();

@@ -178,8 +178,10 @@ __device__ __forceinline__ uint32_t local_ray(const TraceParams& p, uint32_t gid
 
 // Everything CS_TraceRays does after the closest hit is known (shader/CS_TraceRays.hlsl:241-292): light
 // buffers, shading, the scattered ray. tid is the ray's index in this device's buffers.
+// n0, n1: the ray as the call leaves it (the scattered one after a hit, the same one after a miss)
 __device__ __forceinline__ void shade_ray(const TraceParams& p, const ShadeBuffers& b, uint32_t tid, float4 r0, float4 r1,
-                                          const Hit& best, uint32_t best_ci) {
+                                          const Hit& best, uint32_t best_ci, float4& n0, float4& n1) {
+    n0 = r0; n1 = r1;
     const float4 o0 = b.old_rays[2 * (size_t)tid], o1 = b.old_rays[2 * (size_t)tid + 1];
     const f3 org = mk(r0.x, r0.y, r0.z), dir = mk(r0.w, r1.x, r1.y);
     const float tmin_r = r1.z, tmax_r = r1.w;
@@ -260,8 +262,10 @@ __device__ __forceinline__ void shade_ray(const TraceParams& p, const ShadeBuffe
         E.x = newE.x; E.y = newE.y; E.z = newE.z;
 
         // new ray from the hit point; the traced ray becomes the "old" ray, keeping the sample slot in TMax
-        b.rays[2 * (size_t)tid] = make_float4(org.x + dir.x * best.t, org.y + dir.y * best.t, org.z + dir.z * best.t, L.x);
-        b.rays[2 * (size_t)tid + 1] = make_float4(L.y, L.z, tmin_r, tmax_r);
+        n0 = make_float4(org.x + dir.x * best.t, org.y + dir.y * best.t, org.z + dir.z * best.t, L.x);
+        n1 = make_float4(L.y, L.z, tmin_r, tmax_r);
+        b.rays[2 * (size_t)tid] = n0;
+        b.rays[2 * (size_t)tid + 1] = n1;
         b.old_rays[2 * (size_t)tid] = r0;
         b.old_rays[2 * (size_t)tid + 1] = make_float4(r1.x, r1.y, r1.z, o1.w);
     }
@@ -369,7 +373,8 @@ __global__ __launch_bounds__(256) void k_trace(TraceParams p, ShadeBuffers b, co
     }
     if (STATS) add_stats(stats, n_nodes, n_tris, (best.t != tmax_r) ? 1u : 0u, 1u);
     if (missed && best.t == tmax_r) missed[tid] = 1u;
-    shade_ray(p, b, tid, r0, r1, best, best_ci);
+    float4 n0, n1;
+    shade_ray(p, b, tid, r0, r1, best, best_ci, n0, n1);
 }
 
 // ---- wavefront form: persistent traversal kernel + convergent shading kernel ----
@@ -1261,6 +1266,33 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {      // abcd -> a00b00
     v = (v | (v << 2)) & 0x00249249u;
     return v;
 }
+// the key of a ray without a probe: (descending) length of its way through the trunk's box lo / hi in units of the box's
+// diagonal, then the cell of its origin in a 16^3 grid over that box and the cell of its direction; 24 bits, of which
+// the leading key_bits are kept
+__device__ __forceinline__ uint32_t chord_key(const float4 r0, const float4 r1, const float4 lo, const float4 hi, uint32_t cost_bits,
+                                              uint32_t key_bits) {
+    const f3 org = mk(r0.x, r0.y, r0.z), dir = mk(r0.w, r1.x, r1.y);
+    const f3 inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    const uint32_t top_class = (1u << cost_bits) - 1u;
+    const f3 t1 = mul(sub(mk(lo.x, lo.y, lo.z), org), inv_d), t2 = mul(sub(mk(lo.w, hi.x, hi.y), org), inv_d);
+    const float tn = fmaxf(fmaxf(fminf(t1.x, t2.x), fminf(t1.y, t2.y)), fmaxf(fminf(t1.z, t2.z), r1.z));
+    const float tf = fminf(fminf(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)), fminf(fmaxf(t1.z, t2.z), r1.w));
+    const f3 ext = sub(mk(lo.w, hi.x, hi.y), mk(lo.x, lo.y, lo.z));
+    const float diag = sqrtf(dot3(ext, ext)) * sqrtf(dot3(dir, dir));
+    const float part = fmaxf(tf - tn, 0.0f) / diag;           // NaN -> 0 below
+    const uint32_t cost_class = (uint32_t)fminf(fmaxf(part * (float)(top_class + 1u), 0.0f), (float)top_class);
+    const float cx = (r0.x - lo.x) / (lo.w - lo.x), cy = (r0.y - lo.y) / (hi.x - lo.y), cz = (r0.z - lo.z) / (hi.y - lo.z);
+    const uint32_t ox = (uint32_t)fminf(fmaxf(cx * 16.0f, 0.0f), 15.0f);
+    const uint32_t oy = (uint32_t)fminf(fmaxf(cy * 16.0f, 0.0f), 15.0f);
+    const uint32_t oz = (uint32_t)fminf(fmaxf(cz * 16.0f, 0.0f), 15.0f);
+    const uint32_t dx = (uint32_t)fminf(fmaxf(r0.w * 2.0f + 2.0f, 0.0f), 3.0f);
+    const uint32_t dy = (uint32_t)fminf(fmaxf(r1.x * 2.0f + 2.0f, 0.0f), 3.0f);
+    const uint32_t dz = (uint32_t)fminf(fmaxf(r1.y * 2.0f + 2.0f, 0.0f), 3.0f);
+    const uint32_t okey = spread3(ox) | (spread3(oy) << 1) | (spread3(oz) << 2);      // 12 bits
+    const uint32_t dkey = spread3(dx) | (spread3(dy) << 1) | (spread3(dz) << 2);      // 6 bits
+    return (((top_class - cost_class) << (24u - cost_bits)) | (((okey << 6) | dkey) >> (cost_bits - 6u))) >> (24u - key_bits);
+}
+
 __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float4* __restrict__ rays,
                                                   const float4* __restrict__ nodes, const float4* __restrict__ pairs,
                                                   uint32_t first_record, uint32_t num_records, uint32_t record_stride,
@@ -1316,8 +1348,13 @@ __global__ __launch_bounds__(256) void k_ray_keys(uint32_t num_rays, const float
     keys[tid] = make_uint2(key, tid);
 }
 
+// next_keys (optional; never together with missed): the key k_ray_keys would give the ray this call leaves behind, for the
+// next trace call on the same hierarchy - the ray is in registers here, so that call need not read all rays once more.
+// key_nodes: that hierarchy's nodes (the trunk's box).
 __global__ __launch_bounds__(256) void k_shade(TraceParams p, ShadeBuffers b, const float4* __restrict__ hit_records,
-                                               const uint32_t* __restrict__ hit_ci, uint8_t* __restrict__ missed) {
+                                               const uint32_t* __restrict__ hit_ci, uint8_t* __restrict__ missed,
+                                               uint2* __restrict__ next_keys, const float4* __restrict__ key_nodes, uint32_t cost_bits,
+                                               uint32_t key_bits) {
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     if (tid >= p.num_rays) return;
     if (missed && missed[tid]) return;           // not walked by this call: it would have missed again, which changes nothing
@@ -1326,7 +1363,9 @@ __global__ __launch_bounds__(256) void k_shade(TraceParams p, ShadeBuffers b, co
     if (missed && h.x == r1.w) missed[tid] = 1u;
     Hit best;
     best.t = h.x; best.u = h.y; best.v = h.z; best.w = h.w;
-    shade_ray(p, b, tid, r0, r1, best, hit_ci[tid]);
+    float4 n0, n1;
+    shade_ray(p, b, tid, r0, r1, best, hit_ci[tid], n0, n1);
+    if (next_keys) next_keys[tid] = make_uint2(chord_key(n0, n1, key_nodes[0], key_nodes[1], cost_bits, key_bits), tid);
 }
 
 int trace_workspace(rt_device* dev, uint32_t num_rays) {
@@ -1341,6 +1380,7 @@ int trace_workspace(rt_device* dev, uint32_t num_rays) {
     if (dev->listed_rays) { (void)hipFree(dev->listed_rays); dev->listed_rays = nullptr; }
     if (dev->missed) { (void)hipFree(dev->missed); dev->missed = nullptr; }
     dev->missed_valid = false;
+    dev->keys_ready = false;
     dev->hit_capacity = 0;
     hipError_t e = hipMalloc((void**)&dev->hit_records, (size_t)num_rays * 16u);
     if (e == hipSuccess) e = hipMalloc((void**)&dev->hit_ci, (size_t)num_rays * 4u);
@@ -1402,6 +1442,10 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     int rc = rt_set_device(dev);
     if (rc) return rc;
 
+    // keys the last call's shading left for these rays hold for this call only; whatever this call does to the rays, the
+    // keys are its own or none
+    const bool keys_were_ready = dev->keys_ready;
+    dev->keys_ready = false;
     // the traversal kernel and its tuning are device settings (rt_device_set_trace_kernel, rt_device_set_trace_tuning)
     const rt_trace_tuning& tune = dev->tuning;
     const bool divide = dev->slab_division;
@@ -1526,6 +1570,10 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         quads = (const float4*)dev->conv_quads;
     }
     uint2* order = nullptr;
+    // keys for the next call, made by this call's shading kernel (the default kernel's probe-free keys only; not with
+    // dropped rays, whose keys also carry the live count)
+    bool leave_keys = false;
+    uint32_t leave_cost_bits = 0u, leave_key_bits = 0u;
     if (sort_rays) {
         // walk-length estimate from every fourth pair of nodes at depth 10 (or the deepest level above the leaves of a
         // small tree): deeper, smaller boxes tell long walks from short ones better than all the boxes of depth 8 do
@@ -1552,9 +1600,15 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
             if (rc) return rc;
             if (!on_spatial) pairs = key_pairs;
         }
-        hipLaunchKernelGGL(k_ray_keys, grid, block, 0, s, nr, ray_in, key_nodes, key_pairs, 1u << (depth - 1u), (nodes_there + 1u) / 2u,
-                           probe_stride, cost_shift, key_passes == 1u ? 8u : cost_bits, 8u * key_passes, dev->ray_keys_a,
-                           (const uint8_t*)(live ? missed : nullptr), live);
+        const uint32_t key_cost_bits = key_passes == 1u ? 8u : cost_bits, key_bits = 8u * key_passes;
+        leave_keys = on_spatial && chord_only && !missed;
+        leave_cost_bits = key_cost_bits; leave_key_bits = key_bits;
+        const bool have_keys = leave_keys && keys_were_ready && dev->keys_rays == rays->ptr && dev->keys_accel == (const void*)accel &&
+                               dev->keys_count == nr && dev->keys_cost_bits == key_cost_bits && dev->keys_bits == key_bits;
+        if (!have_keys)
+            hipLaunchKernelGGL(k_ray_keys, grid, block, 0, s, nr, ray_in, key_nodes, key_pairs, 1u << (depth - 1u), (nodes_there + 1u) / 2u,
+                               probe_stride, cost_shift, key_cost_bits, key_bits, dev->ray_keys_a, (const uint8_t*)(live ? missed : nullptr),
+                               live);
         rc = rt_sort_pairs(dev, dev->ray_keys_a, dev->ray_keys_b, nr, key_passes, &order);      // 8, 16 or 24-bit keys
         if (rc) return rc;
     }
@@ -1612,8 +1666,17 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     }
     rc = rt_launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_shade, grid, block, 0, s, p, b, (const float4*)dev->hit_records, (const uint32_t*)dev->hit_ci, missed);
-    return rt_launch_status();
+    hipLaunchKernelGGL(k_shade, grid, block, 0, s, p, b, (const float4*)dev->hit_records, (const uint32_t*)dev->hit_ci, missed,
+                       leave_keys ? dev->ray_keys_a : (uint2*)nullptr, leave_keys ? (const float4*)accel->sp_nodes : (const float4*)nullptr,
+                       leave_cost_bits, leave_key_bits);
+    rc = rt_launch_status();
+    if (rc) return rc;
+    if (leave_keys) {
+        dev->keys_ready = true;
+        dev->keys_rays = rays->ptr; dev->keys_accel = (const void*)accel; dev->keys_count = nr;
+        dev->keys_cost_bits = leave_cost_bits; dev->keys_bits = leave_key_bits;
+    }
+    return RT_OK;
 }
 
 }  // namespace
@@ -1642,6 +1705,7 @@ int rt_device_set_drop_missed_rays(rt_device* dev, int enable) {
     if (!dev) return RT_ERR_INVALID_ARGUMENT;
     dev->drop_missed = enable != 0;
     dev->missed_valid = false;
+    dev->keys_ready = false;
     return RT_OK;
 }
 
