@@ -6,7 +6,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 200 python scripts/build_time.py "$N" 20 "$SECOND" > "$OUT/time_${N}_${SECOND}.txt" 2>&1 || { tail -3 "$OUT/time_${N}_${SECOND}.txt"; exit 1; }
 cat "$OUT/time_${N}_${SECOND}.txt"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${N}_${SECOND}" -o p -- python scripts/build_time.py "$N" 20 "$SECOND" > /dev/null 2> "$OUT/rocprof_${N}_${SECOND}.err" || { tail -3 "$OUT/rocprof_${N}_${SECOND}.err"; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${N}_${SECOND}" -o p -- python scripts/build_time.py "$N" 20 "$SECOND" 0 > /dev/null 2> "$OUT/rocprof_${N}_${SECOND}.err" || { tail -3 "$OUT/rocprof_${N}_${SECOND}.err"; exit 1; }
 python - "$OUT/prof_${N}_${SECOND}/p_kernel_stats.csv" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
