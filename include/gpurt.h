@@ -285,7 +285,11 @@ int rt_accel_refit(rt_accel* accel, rt_buffer* bvh);
  * copied. */
 int rt_synthetic_animate(rt_device* dev, uint32_t num_primitives, uint32_t frame, const rt_buffer* base_vertices,
                          rt_buffer* vertices);
-/* rt_trace_rays reading the accel's Morton-ordered packed triangles instead of Indices -> Vertices. */
+/* rt_trace_rays reading the accel's Morton-ordered packed triangles instead of Indices -> Vertices.
+ * State kept between calls on a device (none of it enters a result): with the SPATIAL kernel a call also leaves the
+ * sort keys of the rays it scattered for the next call - used there if that call traces the same ray buffer with the
+ * same accel and settings, made afresh otherwise; rt_camera_ray_generation and builds discard them. Keys only decide the
+ * order rays are traced in. */
 int rt_trace_rays_accel(rt_device* dev, const rt_trace_rays_info* info, const rt_accel* accel, const rt_buffer* indices,
                         const rt_buffer* vertices, const rt_buffer* materials, const rt_buffer* texture_ids,
                         const rt_buffer* texture_atlas, uint32_t atlas_elements, rt_buffer* rays, rt_buffer* old_rays,
