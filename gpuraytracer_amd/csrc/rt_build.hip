@@ -1517,7 +1517,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     const SceneBounds spb = make_bounds(scene_min, scene_max);
     if (own) {
         RT_HIP(hipMemsetAsync(a->cells + RT_CELLS_AXIS, 0, (size_t)3u * RT_AXIS_STEPS * sizeof(uint32_t), s));
-        const uint32_t stride = n > (1u << 20) ? (n >> 20) + 1u : 1u;         // about a million samples are plenty
+        const uint32_t stride = n > (1u << 18) ? (n >> 18) + 1u : 1u;         // a quarter of a million samples are plenty for 4096 steps
         const uint32_t samples = div_up(n, stride);
         hipLaunchKernelGGL(k_axis_hist, dim3(min(div_up(samples, 256u), 512u)), dim3(256), 0, s, spb, dbounds, n, stride, a->tris, a->cells);
         hipLaunchKernelGGL(k_axis_map, dim3(3), dim3(1024), 0, s, samples, a->cells);
