@@ -277,8 +277,13 @@ __device__ __forceinline__ uint32_t spatial_key(float cx, float cy, float cz, co
 // cell (or half, or a quarter of one), and only inside a cell are leaves laid out by rank. T is the largest of
 // 21, 18, ... 3 whose fullest cell still fits its slots (two triangles per slot); 0 = by rank, as the reference.
 // cells: see RT_CELLS_* in rt_internal.h; all of it is zero before k_cell_hist.
+// (outliers - see RT_CELLS_OUTLIERS - carry the largest key, sort behind every other triangle and belong to no cell)
+__device__ __forceinline__ uint32_t without_outliers(uint32_t n, const uint32_t* __restrict__ cells) {
+    return n - min(min(cells[RT_CELLS_OUTLIERS], RT_OUTLIERS_MAX), n);
+}
 __global__ __launch_bounds__(256) void k_cell_hist(uint32_t n, const uint2* __restrict__ sorted, uint32_t* __restrict__ cells) {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    n = without_outliers(n, cells);
     // the keys are sorted: neighbouring lanes mostly fall into the same cell, and one lane per run of equal cells adds
     // the run's length (one atomic per triangle on a word its neighbours want too costs ten times as much)
     const uint32_t cell = r < n ? sorted[r].x >> (30u - RT_CELL_BITS_MAX) : 0xffffffffu;
@@ -374,6 +379,8 @@ __device__ __forceinline__ void cell_run(uint32_t* __restrict__ cells, uint32_t 
 }
 __global__ __launch_bounds__(256) void k_cell_starts(uint32_t n, const uint2* __restrict__ sorted, uint32_t* __restrict__ cells) {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    n = without_outliers(n, cells);
+    if (n == 0u && r == 0u) cell_run(cells, 0u, 1u << cells[0], 0u);      // nothing but outliers: every cell is empty
     if (r >= n) return;
     const uint32_t T = cells[0], shift = 30u - T;          // codes have 30 bits: T = 0 puts everything into cell 0
     const uint32_t c = sorted[r].x >> shift;
@@ -817,7 +824,7 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
                                                 const uint32_t* __restrict__ cells, uint32_t slots_log2,
                                                 const float4* __restrict__ ref_leaves, float sliver_pad,
                                                 uint2* __restrict__ own_keys, SceneBounds sb, const float* __restrict__ dbounds,
-                                                const uint32_t* __restrict__ axis_map) {
+                                                const uint32_t* __restrict__ axis_map, uint32_t* __restrict__ outliers) {
     // Two builds use the extras. The reference's hierarchy, when the library's own is to follow: own_keys receives, for
     // the sorted entries 2g and 2g + 1, (key of the own hierarchy, place in the reference's order) - the corners are in
     // registers here, so the second sort needs no pass of its own over the triangles. The library's own hierarchy:
@@ -912,9 +919,26 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
             for (int t = 0; t < 2; t++)
 #pragma unroll
                 for (int a = 0; a < 3; a++) cen[t][a] = 0.333333f * ((corner[3 * t][a] + corner[3 * t + 1][a]) + corner[3 * t + 2][a]);
-            const uint2 k0 = make_uint2(spatial_key(cen[0][0], cen[0][1], cen[0][2], sb, axis_map), r0);
-            if (two) *reinterpret_cast<uint4*>(own_keys + r0) = make_uint4(k0.x, k0.y, spatial_key(cen[1][0], cen[1][1], cen[1][2], sb, axis_map), r0 + 1u);
-            else own_keys[r0] = k0;
+            uint32_t key[2] = {spatial_key(cen[0][0], cen[0][1], cen[0][2], sb, axis_map), spatial_key(cen[1][0], cen[1][1], cen[1][2], sb, axis_map)};
+            // An outlier: a triangle whose box has a sixteenth or more of the surface of the box of all centroids. It goes on
+            // the list (while there is room) and gets the largest key, behind every triangle of the hierarchy.
+            const float sx = sb.mx[0] - sb.mn[0], sy = sb.mx[1] - sb.mn[1], sz = sb.mx[2] - sb.mn[2];
+            const float scene_area = (sx * sy + sy * sz) + sz * sx;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                if (t == 1 && !two) break;
+                const float* c0 = corner[3 * t]; const float* c1 = corner[3 * t + 1]; const float* c2 = corner[3 * t + 2];
+                const float ex = fmaxf(fmaxf(c0[0], c1[0]), c2[0]) - fminf(fminf(c0[0], c1[0]), c2[0]);
+                const float ey = fmaxf(fmaxf(c0[1], c1[1]), c2[1]) - fminf(fminf(c0[1], c1[1]), c2[1]);
+                const float ez = fmaxf(fmaxf(c0[2], c1[2]), c2[2]) - fminf(fminf(c0[2], c1[2]), c2[2]);
+                const float area = (ex * ey + ey * ez) + ez * ex;
+                if (scene_area > 0.0f && area * 16.0f >= scene_area) {
+                    const uint32_t at = atomicAdd(outliers, 1u);
+                    if (at < RT_OUTLIERS_MAX) { outliers[1u + at] = r0 + (uint32_t)t; key[t] = 0xffffffffu; }
+                }
+            }
+            if (two) *reinterpret_cast<uint4*>(own_keys + r0) = make_uint4(key[0], r0, key[1], r0 + 1u);
+            else own_keys[r0] = make_uint2(key[0], r0);
         }
         if (PACKED) leaf_triangle_record(s_tri + 5u * threadIdx.x, corner, ci0, ci1);
         if (cells) {
@@ -967,6 +991,47 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
         }
     }
     if (FUSED) upsweep_block(b, 0u, lv, nodes, pairs, quads, s_box);
+}
+
+// The outliers of a build (RT_CELLS_OUTLIERS) as leaf records for k_traverse_spatial: in ascending order of their places in
+// the reference's order, two per record, corners and index slots from the reference's leaf records. One wave.
+__global__ __launch_bounds__(64) void k_outlier_leaves(const uint32_t* __restrict__ cells, const float4* __restrict__ ref_leaves,
+                                                       float4* __restrict__ out) {
+    __shared__ uint32_t s_place[RT_OUTLIERS_MAX + 1u];
+    static_assert(RT_OUTLIERS_MAX == 64u, "one lane per outlier");
+    const uint32_t lane = threadIdx.x;
+    const uint32_t count = min(cells[RT_CELLS_OUTLIERS], RT_OUTLIERS_MAX);
+    const uint32_t mine = lane < count ? cells[RT_CELLS_OUTLIERS + 1u + lane] : 0xffffffffu;
+    uint32_t rank = 0u;                                   // places are distinct: the rank is a permutation
+    for (int j = 0; j < 64; j++) rank += ((uint32_t)__shfl((int)mine, j, 64) < mine) ? 1u : 0u;
+    s_place[lane] = 0xffffffffu;
+    if (lane == 0u) s_place[RT_OUTLIERS_MAX] = 0xffffffffu;
+    __syncthreads();
+    if (lane < count) s_place[rank] = mine;
+    __syncthreads();
+    if (2u * lane >= count) return;
+    const uint32_t place0 = s_place[2u * lane], place1 = s_place[2u * lane + 1u];
+    float corner[6][3];
+    uint32_t ci0 = 0u, ci1 = 0xffffffffu;
+#define RT_REF_TRIANGLE(PLACE, K, CI)                                                                                          \
+    {                                                                                                                          \
+        const float4* l = ref_leaves + RT_LEAF_STRIDE * (size_t)((PLACE) >> 1);                                                \
+        const float4 l0 = l[0], l1 = l[1], l2 = l[2], l3 = l[3], l4 = l[4];                                                    \
+        const bool second = ((PLACE) & 1u) != 0u;                                                                              \
+        corner[K][0] = second ? l0.y : l0.x; corner[K][1] = second ? l0.w : l0.z; corner[K][2] = second ? l1.y : l1.x;         \
+        corner[K + 1][0] = second ? l1.w : l1.z; corner[K + 1][1] = second ? l2.y : l2.x; corner[K + 1][2] = second ? l2.w : l2.z; \
+        corner[K + 2][0] = second ? l3.y : l3.x; corner[K + 2][1] = second ? l3.w : l3.z; corner[K + 2][2] = second ? l4.y : l4.x; \
+        CI = __float_as_uint(second ? l4.w : l4.z);                                                                            \
+    }
+    RT_REF_TRIANGLE(place0, 0, ci0)
+    if (place1 != 0xffffffffu) RT_REF_TRIANGLE(place1, 3, ci1)
+#undef RT_REF_TRIANGLE
+    if (place1 == 0xffffffffu)
+        for (int i = 0; i < 3; i++) { corner[3 + i][0] = corner[i][0]; corner[3 + i][1] = corner[i][1]; corner[3 + i][2] = corner[i][2]; }
+    float4* o = out + RT_LEAF_STRIDE * (size_t)lane;
+    leaf_triangle_record(o, corner, ci0, ci1);
+    o[5] = make_float4(__uint_as_float(place0), __uint_as_float(place1), 0.0f, 0.0f);
+    o[6] = o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // continues the up-sweep from level k0 (already in memory), eight levels per launch
@@ -1243,7 +1308,7 @@ int rt_bvh_build_leaves(rt_device* dev, const rt_bvh_info* info, const rt_buffer
                        (const uint32_t*)morton_codes->ptr, (const uint32_t*)indices->ptr, (const rt_vertex*)vertices->ptr,
                        (const float4*)nullptr, (float4*)nullptr, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, (float4*)nullptr,
                        (const uint32_t*)nullptr, 0u, (const float4*)nullptr, 0.0f, (uint2*)nullptr, SceneBounds{}, (const float*)nullptr,
-                       (const uint32_t*)nullptr);
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr);
     return rt_launch_status();
 }
 
@@ -1277,6 +1342,7 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
     a->keys_a = a->keys_b = nullptr;
     a->pairs = a->sp_pairs = a->sp_nodes = nullptr;
     a->cells = nullptr;
+    a->outlier_leaves = nullptr;
     a->pairs_valid = a->sp_pairs_valid = false;
     a->sp_built = false;
     a->built_prims = 0;
@@ -1308,6 +1374,7 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
         if (e == hipSuccess) e = hipMalloc((void**)&a->sp_tris, (size_t)slots * RT_LEAF_STRIDE * sizeof(float4));
     }
     if (e == hipSuccess) e = hipMalloc((void**)&a->cells, (size_t)RT_CELLS_WORDS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&a->outlier_leaves, (size_t)(RT_OUTLIERS_MAX / 2u) * RT_LEAF_STRIDE * sizeof(float4));
     if (e != hipSuccess) {
         rt_accel_destroy(a);
         return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
@@ -1331,6 +1398,7 @@ int rt_accel_destroy(rt_accel* a) {
     if (a->sp_quads) (void)hipFree(a->sp_quads);
     if (a->sp_tris) (void)hipFree(a->sp_tris);
     if (a->cells) (void)hipFree(a->cells);
+    if (a->outlier_leaves) (void)hipFree(a->outlier_leaves);
     delete a;
     return RT_OK;
 }
@@ -1472,10 +1540,12 @@ int rt_accel_refit(rt_accel* a, rt_buffer* bvh) {
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)order,
                        (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr,
                        a->quads, (const uint32_t*)nullptr, 0u, (const float4*)nullptr, 0.0f, (uint2*)nullptr, none, (const float*)nullptr,
-                       (const uint32_t*)nullptr);
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr);
     for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
         hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, a->quads);
     if (!own) return rt_launch_status();
+    // the same outliers as at the last build, from the refitted leaf records
+    hipLaunchKernelGGL(k_outlier_leaves, dim3(1), dim3(64), 0, s, (const uint32_t*)a->cells, (const float4*)a->sorted_tris, a->outlier_leaves);
     // the library's own hierarchy: same slots, same pairs of triangles, corners from the leaf records written above
     const uint32_t slots = rt_spatial_slots(n);
     uint32_t slots_log2 = 0u;
@@ -1484,7 +1554,7 @@ int rt_accel_refit(rt_accel* a, rt_buffer* bvh) {
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(slots, 256u)), dim3(256), 0, s, 2u * slots, sl, (const uint32_t*)a->sp_sorted,
                        (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads,
                        (const uint32_t*)a->cells, slots_log2, (const float4*)a->sorted_tris, dev->walk_sliver_pad, (uint2*)nullptr, none,
-                       (const float*)nullptr, (const uint32_t*)nullptr);
+                       (const float*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     for (uint32_t k0 = 8u; k0 + 1u < sl.count; k0 += 8u)
         hipLaunchKernelGGL(k_upsweep, dim3(div_up(sl.n[k0], 256u)), dim3(256), 0, s, k0, sl, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads);
     return rt_launch_status();
@@ -1516,7 +1586,9 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     const bool own = a->want_spatial && a->sp_tris != nullptr;
     const SceneBounds spb = make_bounds(scene_min, scene_max);
     if (own) {
-        RT_HIP(hipMemsetAsync(a->cells + RT_CELLS_AXIS, 0, (size_t)3u * RT_AXIS_STEPS * sizeof(uint32_t), s));
+        // (the per-axis histograms and, right behind them, the count of outliers)
+        static_assert(RT_CELLS_OUTLIERS == RT_CELLS_AXIS + 3u * RT_AXIS_STEPS, "one memset clears both");
+        RT_HIP(hipMemsetAsync(a->cells + RT_CELLS_AXIS, 0, (size_t)(3u * RT_AXIS_STEPS + 1u) * sizeof(uint32_t), s));
         const uint32_t stride = n > (1u << 18) ? (n >> 18) + 1u : 1u;         // a quarter of a million samples are plenty for 4096 steps
         const uint32_t samples = div_up(n, stride);
         hipLaunchKernelGGL(k_axis_hist, dim3(min(div_up(samples, 256u), 512u)), dim3(256), 0, s, spb, dbounds, n, stride, a->tris, a->cells);
@@ -1532,7 +1604,8 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)src,
                        (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr,
                        a->quads, (const uint32_t*)nullptr, 0u, (const float4*)nullptr, 0.0f, own ? other : (uint2*)nullptr, spb, dbounds,
-                       (const uint32_t*)(a->cells + RT_CELLS_AXIS));
+                       (const uint32_t*)(a->cells + RT_CELLS_AXIS), a->cells + RT_CELLS_OUTLIERS);
+    if (own) hipLaunchKernelGGL(k_outlier_leaves, dim3(1), dim3(64), 0, s, (const uint32_t*)a->cells, (const float4*)a->sorted_tris, a->outlier_leaves);
     for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
         hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, a->quads);
     if (morton_codes)
@@ -1562,7 +1635,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(slots, 256u)), dim3(256), 0, s, 2u * slots, sl, (const uint32_t*)sp_src,
                        (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads,
                        (const uint32_t*)a->cells, slots_log2, (const float4*)a->sorted_tris, dev->walk_sliver_pad, (uint2*)nullptr, spb,
-                       (const float*)nullptr, (const uint32_t*)nullptr);
+                       (const float*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     for (uint32_t k0 = 8u; k0 + 1u < sl.count; k0 += 8u)
         hipLaunchKernelGGL(k_upsweep, dim3(div_up(sl.n[k0], 256u)), dim3(256), 0, s, k0, sl, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads);
     return rt_launch_status();

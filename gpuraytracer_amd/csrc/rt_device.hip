@@ -35,6 +35,7 @@ int rt_device_create(int gpu_index, rt_device** out) {
     d->ray_keys_b = nullptr;
     d->listed_rays = nullptr;
     d->walk_stats = nullptr;
+    d->walk_stats_hist = false;
     d->conv_pairs = nullptr;
     d->conv_tris = nullptr;
     d->conv_quads = nullptr;

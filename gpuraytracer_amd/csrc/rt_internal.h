@@ -16,6 +16,7 @@ struct rt_device {
     size_t sort_table_words;
     uint32_t* sort_totals;     // [256] digit totals + [256] exclusive digit bases
     unsigned long long* trace_stats;   // optional traversal counters (rt_device_set_trace_stats)
+    bool walk_stats_hist;              // the walk_stats buffer holds 20 counters (steps by depth behind the first four)
     unsigned long long* walk_stats;    // optional counters of the walk on the library's own hierarchy (rt_device_set_walk_stats)
     // workspace of the wavefront trace: closest-hit records between the traversal and shading kernels
     float4* hit_records;       // [hit_capacity] (t, u, v, facing)
@@ -216,6 +217,7 @@ struct rt_accel {
     uint32_t built_prims;      // triangles of the last build (0: none yet) - what rt_accel_refit may refit
     uint2* sp_sorted;          // keys_a or keys_b: the own hierarchy's sorted (key, place) pairs of the last build
     rt_levels sp_lv;           // shape of that hierarchy at the last build: rt_spatial_slots(num_prims) leaves, all levels full
+    float4* outlier_leaves;    // [RT_LEAF_STRIDE * RT_OUTLIERS_MAX / 2] the outliers (see RT_CELLS_OUTLIERS) as leaf records, two per record
 };
 // rt_accel::cells, in uint32 (everything before RT_CELLS_START is cleared by every build): [0..7] layout {cell bits T, largest cell at T = 21, 18, ... 3}; then the triangles per cell
 // of the finest level, the cells of 15 bits summed from them, and the first rank of every cell at the chosen level
@@ -226,6 +228,13 @@ constexpr uint32_t RT_CELLS_START = RT_CELLS_HIST12 + (1u << (RT_CELL_BITS_MAX -
 // 10-bit coordinate the keys are made of (k_axis_map)
 constexpr uint32_t RT_AXIS_STEPS = 4096u;
 constexpr uint32_t RT_CELLS_AXIS = RT_CELLS_START + (1u << RT_CELL_BITS_MAX) + 1u;
-constexpr uint32_t RT_CELLS_WORDS = RT_CELLS_AXIS + 3u * RT_AXIS_STEPS;
+// ... and the outliers of the last build: triangles whose box is a large part of the scene's (a wall, a floor). In a
+// hierarchy they make every node above them as large as they are, and every ray meets those nodes; the library's own
+// hierarchy leaves them out, and k_traverse_spatial tests them from a list before a ray's walk starts.
+// [RT_CELLS_OUTLIERS] = how many were found (more than RT_OUTLIERS_MAX: the others stay in the hierarchy), then their
+// places in the reference's order, in the order found.
+constexpr uint32_t RT_OUTLIERS_MAX = 64u;
+constexpr uint32_t RT_CELLS_OUTLIERS = RT_CELLS_AXIS + 3u * RT_AXIS_STEPS;
+constexpr uint32_t RT_CELLS_WORDS = RT_CELLS_OUTLIERS + 1u + RT_OUTLIERS_MAX;
 
 #endif

@@ -53,6 +53,7 @@ struct TraceParams {
     uint32_t deal_shift;       // blocks of 2^deal_shift consecutive positions of the ray order are dealt to the queues in turn
     float beyond;              // k_traverse_spatial enters boxes up to reach * beyond
     uint32_t trunk_children;   // node index (reference layout) of the first of the trunk's two children, for hierarchy lv
+    uint32_t walk_hist;        // counting variant of k_traverse_spatial: the counter buffer also has room for steps by depth
     rt_levels lv;
 };
 
@@ -950,7 +951,81 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
 // triangles in the faces of flat boxes, overlapping coplanar triangles - are inside the margin and end on the list
 // (scripts/fuzz_walks.py compares the two walks over random scenes of these kinds).
 
-constexpr uint32_t kStockFields = 14u;     // origin, direction, reciprocals, tmin, tmax, ray, first node, noted sibling
+// origin, direction, reciprocals, tmin, tmax, ray, first node, noted sibling (+ bit 31: walk again in the reference's
+// order), and what the outliers have left: closest hit (t, u, v, facing), its index slot and place, reach, runner-up
+constexpr uint32_t kStockFields = 22u;
+
+// What a lane of k_traverse_spatial knows about its ray's hits. Beyond the closest hit: its place in the reference's
+// order, the distance up to which boxes are still entered (the larger of the hit's distance and the entry distance of
+// its leaf's box in the reference's hierarchy), the smallest distance of any other hit seen, and whether the ray has
+// to be walked again in the reference's order.
+struct WalkHits {
+    Hit best;
+    uint32_t best_ci, best_rank;      // best_rank 0xffffffff: no hit yet
+    float reach, runner_up;
+    // Boxes are entered up to a little beyond reach: a triangle's hit distance and the entry distance of a box around
+    // it are two roundings of (nearly) the same number - the same one for a triangle in the face of a flat box - and
+    // a hit that is closer than the closest one by a rounding must not be lost behind a box that is farther by one.
+    float reach_in;
+    bool again;
+};
+__device__ __forceinline__ void walk_hits_start(WalkHits& s, float tmax_r, float beyond) {
+    s.best.t = tmax_r; s.best.u = 0.0f; s.best.v = 0.0f; s.best.w = 0.0f;
+    s.best_ci = 0u; s.best_rank = 0xffffffffu;
+    s.reach = tmax_r; s.runner_up = __builtin_inff();
+    s.reach_in = tmax_r * beyond;
+    s.again = false;
+}
+// a triangle that the ray hits at hk (index slot ck, place `rank` in the reference's order), found in whatever order
+__device__ __forceinline__ void walk_hits_consider(WalkHits& s, const Hit& hk, uint32_t ck, uint32_t rank, f3 org, f3 inv_d, float lim,
+                                                   float tmax_r, float beyond, const char* __restrict__ ref_leaf_bytes) {
+    if (!(hk.t <= s.reach)) return;
+    // The reference tests this triangle only if the box of ITS leaf of the triangle lets the ray in: that leaf is the
+    // pair of neighbours in the reference's order.
+    const float4* rt = reinterpret_cast<const float4*>(ref_leaf_bytes + (size_t)(rank >> 1) * 128u);
+    const float entry = leaf_box_entry(org, inv_d, lim, rt[0], rt[1], rt[2], rt[3], rt[4]);
+    if (!(entry < __builtin_inff())) return;
+    const bool have_hit = s.best_rank != 0xffffffffu;
+    const float far_end = fmaxf(entry, hk.t);
+    const bool closer = !have_hit || hk.t < s.best.t || (hk.t == s.best.t && rank < s.best_rank);
+    if (!closer) {
+        s.runner_up = fminf(s.runner_up, hk.t);
+    } else if (have_hit ? far_end <= s.reach : far_end < tmax_r) {
+        if (have_hit) s.runner_up = fminf(s.runner_up, s.best.t);
+        s.best = hk; s.best_ci = ck; s.best_rank = rank; s.reach = far_end;
+        s.reach_in = s.reach * beyond;
+    } else if (have_hit) {
+        s.again = true;          // a hit that is closer, behind a box entry that is not
+    }
+}
+// the two triangles of a leaf record (l0 .. l4; places: theirs in the reference's order)
+__device__ __forceinline__ void walk_hits_leaf(WalkHits& s, f3 org, f3 dir, f3 inv_d, float tmin_r, float tmax_r, float lim, float beyond,
+                                               float4 l0, float4 l1, float4 l2, float4 l3, float4 l4, float2 places,
+                                               const char* __restrict__ ref_leaf_bytes) {
+    const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
+    Hit h0, h1;
+    intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
+    const bool may0 = (tmin_r <= h0.t) && (tmax_r > h0.t) && (h0.t <= s.reach);
+    const bool may1 = (ci1 != 0xffffffffu) && (tmin_r <= h1.t) && (tmax_r > h1.t) && (h1.t <= s.reach);
+    // few leaves have a triangle that is hit, fewer two: one turn of this loop per such triangle
+#pragma unroll 1
+    for (uint32_t todo = (may0 ? 1u : 0u) | (may1 ? 2u : 0u); todo != 0u; todo &= todo - 1u) {
+        const bool k = (todo & 1u) == 0u;         // the second triangle's turn
+        Hit hk;
+        hk.t = k ? h1.t : h0.t; hk.u = k ? h1.u : h0.u; hk.v = k ? h1.v : h0.v; hk.w = k ? h1.w : h0.w;
+        walk_hits_consider(s, hk, k ? ci1 : ci0, __float_as_uint(k ? places.y : places.x), org, inv_d, lim, tmax_r, beyond, ref_leaf_bytes);
+    }
+}
+// a finished ray leaves its closest hit behind; a ray for which the reference's order decides goes on the list
+__device__ __forceinline__ void walk_hits_finish(WalkHits& s, uint32_t ray, float4* __restrict__ hit_records, uint32_t* __restrict__ hit_ci,
+                                                 uint2* __restrict__ flagged, uint32_t* __restrict__ flag_count) {
+    hit_records[ray] = make_float4(s.best.t, s.best.u, s.best.v, s.best.w);
+    hit_ci[ray] = s.best_ci;
+    // the closest hit lies before the entry of its leaf's box and another hit lies in between: which of
+    // them the reference keeps depends on the order it meets them in
+    if (s.best_rank != 0xffffffffu && s.reach > s.best.t && s.runner_up <= s.reach) s.again = true;
+    if (s.again) flagged[atomicAdd(flag_count, 1u)] = make_uint2(0u, ray);
+}
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const float4* __restrict__ rays, const float4* __restrict__ nodes,
@@ -960,7 +1035,8 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                                                        const uint2* __restrict__ order, const float4* __restrict__ ref_tris,
                                                        uint2* __restrict__ flagged,
                                                        uint32_t* __restrict__ flag_count, unsigned long long* __restrict__ walk_stats,
-                                                       const uint32_t* __restrict__ live) {
+                                                       const uint32_t* __restrict__ live, const float4* __restrict__ outlier_leaves,
+                                                       const uint32_t* __restrict__ outlier_count) {
     extern __shared__ uint32_t s_dyn[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     uint32_t num_rays = p.num_rays, queue_chunk = p.queue_chunk;      // (the kernel argument itself stays untouched: in registers)
@@ -989,26 +1065,23 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
     f3 inv_w = org;                   // reciprocals used with the widened boxes: finite where the direction is zero
     bool neg_x = false, neg_y = false, neg_z = false;      // the ray travels downwards on that axis
     float tmin_r = 0.0f, tmax_r = 0.0f, lim = 0.0f;
-    Hit best;
-    best.t = 0.0f; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
-    uint32_t best_ci = 0u;
-    // Beyond the closest hit: its place in the reference's order, the distance up to which boxes are still entered
-    // (the larger of the hit's distance and the entry distance of its leaf's box in the reference's hierarchy),
-    // the smallest distance of any other hit seen, and whether the ray has to be walked again in the reference's order.
-    uint32_t best_rank = 0xffffffffu;
-    float reach = 0.0f, runner_up = 0.0f;
-    // Boxes are entered up to a little beyond reach: a triangle's hit distance and the entry distance of a box around
-    // it are two roundings of (nearly) the same number - the same one for a triangle in the face of a flat box - and
-    // a hit that is closer than the closest one by a rounding must not be lost behind a box that is farther by one.
-    float reach_in = 0.0f;
+    WalkHits hits;
+    walk_hits_start(hits, 0.0f, 1.0f);
     const float kBeyond = p.beyond;             // 1 + 2^-8 unless a test has asked for less (rt_device_set_walk_margins)
-    bool have_hit = false, again = false;
+    // leaf records of the build's outliers (triangles the hierarchy leaves out), tested before a ray's walk starts
+    const uint32_t outlier_records = (min(*outlier_count, RT_OUTLIERS_MAX) + 1u) / 2u;
     uint32_t h = 1u;                  // slot of the entered node
     unsigned long long trail = 0ull;
     uint32_t wait_head = 0u;
     uint32_t q = blockIdx.x & 7u, queues_tried = 0u;       // wave-uniform
     uint32_t n_steps = 0u, n_empty = 0u, n_leaves = 0u;    // COUNT: this wave's steps, steps that hit nothing, leaves tested
     uint32_t n_turns = 0u, n_rounds = 0u;                  // COUNT: turns of the walking loop and triangle rounds of this wave
+    // COUNT: this wave's steps by depth of the entered node (two levels per entry: slot 1 is depth 0)
+    uint32_t* s_hist = s_dyn + kFifo * 512u + 4u * kStockFields * 64u + (tid >> 6) * 16u;
+    if (COUNT) {
+        if (lane < 16u) s_hist[lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
 
     for (;;) {
         // 1. Lanes without a ray take one from the wave's stock in LDS. The stock is filled 64 rays at a time by the
@@ -1033,32 +1106,49 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                 f3 c_org = mk(0.0f, 0.0f, 0.0f), c_dir = c_org, c_inv = c_org;
                 float c_tmin = 0.0f, c_tmax = 0.0f;
                 uint32_t c_rid = 0u, c_h = 1u, c_trail = 0u;
+                WalkHits c_hits;
+                walk_hits_start(c_hits, 0.0f, 1.0f);
+                bool valid = false;
                 if (mine < q_end) {
                     const uint32_t slot = mine - q_begin;
                     const uint32_t pos = (((slot >> p.deal_shift) * 8u + q) << p.deal_shift) | (slot & ((1u << p.deal_shift) - 1u));
                     if (pos < num_rays) {
+                        valid = true;
                         c_rid = order ? order[pos].y : pos;
                         const float4 r0 = rays[2 * (size_t)c_rid], r1 = rays[2 * (size_t)c_rid + 1];
                         c_org = mk(r0.x, r0.y, r0.z); c_dir = mk(r0.w, r1.x, r1.y);
                         c_tmin = r1.z; c_tmax = r1.w;
                         c_inv = mk(1.0f / c_dir.x, 1.0f / c_dir.y, 1.0f / c_dir.z);
-                        // the trunk is entered on any box hit
-                        keep = slab(c_org, c_inv, c_tmin, c_tmax, root_lo, root_hi) != 1e30f;
-                        if (keep && odd_first) {
-                            // the trunk's two children, exact boxes, from the nodes in the reference's layout
-                            const float4* c = nodes + 2 * (size_t)p.trunk_children;
-                            const float bt0 = slab(c_org, c_inv, c_tmin, c_tmax, c[0], c[1]), bt1 = slab(c_org, c_inv, c_tmin, c_tmax, c[2], c[3]);
-                            const bool hit0 = (bt0 != 1e30f) && (bt0 < c_tmax);
-                            const bool hit1 = (bt1 != 1e30f) && (bt1 < c_tmax);
-                            keep = hit0 || hit1;
-                            c_h = hit0 ? 2u : 3u;
-                            c_trail = (hit0 && hit1) ? 8u : 0u;
-                        }
-                        if (!keep) {                               // nothing to walk: the ray's record is that of a miss
-                            hit_records[c_rid] = make_float4(c_tmax, 0.0f, 0.0f, 0.0f);
-                            hit_ci[c_rid] = 0u;
-                        }
+                        walk_hits_start(c_hits, c_tmax, kBeyond);
                     }
+                }
+                if (outlier_records) {
+                    // the outliers first, by every lane that has a ray (the records' addresses are the same for all lanes):
+                    // a scene's walls and floor bound the reach of most rays before the walk begins
+                    const float c_lim = (c_tmin > 0.0f) ? c_tmin : __uint_as_float(1u);
+                    for (uint32_t j = 0u; j < outlier_records; j++) {
+                        const float4* t = outlier_leaves + RT_LEAF_STRIDE * j;
+                        const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
+                        const float2 places = *reinterpret_cast<const float2*>(t + 5);
+                        if (valid)
+                            walk_hits_leaf(c_hits, c_org, c_dir, c_inv, c_tmin, c_tmax, c_lim, kBeyond, l0, l1, l2, l3, l4, places, ref_leaf_bytes);
+                    }
+                }
+                if (valid) {
+                    // the trunk is entered on any box hit within reach
+                    keep = slab(c_org, c_inv, c_tmin, c_hits.reach_in, root_lo, root_hi) != 1e30f;
+                    if (keep && odd_first) {
+                        // the trunk's two children, exact boxes, from the nodes in the reference's layout
+                        const float4* c = nodes + 2 * (size_t)p.trunk_children;
+                        const float bt0 = slab(c_org, c_inv, c_tmin, c_tmax, c[0], c[1]), bt1 = slab(c_org, c_inv, c_tmin, c_tmax, c[2], c[3]);
+                        const bool hit0 = (bt0 != 1e30f) && (bt0 <= c_hits.reach_in);
+                        const bool hit1 = (bt1 != 1e30f) && (bt1 <= c_hits.reach_in);
+                        keep = hit0 || hit1;
+                        c_h = hit0 ? 2u : 3u;
+                        c_trail = (hit0 && hit1) ? 8u : 0u;
+                    }
+                    // nothing to walk: the ray's record is what the outliers have left, or that of a miss
+                    if (!keep) walk_hits_finish(c_hits, c_rid, hit_records, hit_ci, flagged, flag_count);
                 }
                 const unsigned long long kept = __builtin_amdgcn_ballot_w64(keep);
                 if (keep) {
@@ -1067,7 +1157,11 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                     e[3 * 64] = c_dir.x; e[4 * 64] = c_dir.y; e[5 * 64] = c_dir.z;
                     e[6 * 64] = c_inv.x; e[7 * 64] = c_inv.y; e[8 * 64] = c_inv.z;
                     e[9 * 64] = c_tmin; e[10 * 64] = c_tmax;
-                    e[11 * 64] = __uint_as_float(c_rid); e[12 * 64] = __uint_as_float(c_h); e[13 * 64] = __uint_as_float(c_trail);
+                    e[11 * 64] = __uint_as_float(c_rid); e[12 * 64] = __uint_as_float(c_h);
+                    e[13 * 64] = __uint_as_float(c_trail | (c_hits.again ? 0x80000000u : 0u));
+                    e[14 * 64] = c_hits.best.t; e[15 * 64] = c_hits.best.u; e[16 * 64] = c_hits.best.v; e[17 * 64] = c_hits.best.w;
+                    e[18 * 64] = __uint_as_float(c_hits.best_ci); e[19 * 64] = __uint_as_float(c_hits.best_rank);
+                    e[20 * 64] = c_hits.reach; e[21 * 64] = c_hits.runner_up;
                 }
                 stock_next = 0u;
                 stock_count = (uint32_t)__popcll(kept);
@@ -1081,16 +1175,18 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                     org = mk(e[0 * 64], e[1 * 64], e[2 * 64]); dir = mk(e[3 * 64], e[4 * 64], e[5 * 64]);
                     inv_d = mk(e[6 * 64], e[7 * 64], e[8 * 64]);
                     tmin_r = e[9 * 64]; tmax_r = e[10 * 64];
-                    ray = __float_as_uint(e[11 * 64]); h = __float_as_uint(e[12 * 64]); trail = (unsigned long long)__float_as_uint(e[13 * 64]);
+                    ray = __float_as_uint(e[11 * 64]); h = __float_as_uint(e[12 * 64]);
+                    const uint32_t noted = __float_as_uint(e[13 * 64]);
+                    trail = (unsigned long long)(noted & 0x7fffffffu);
                     lim = (tmin_r > 0.0f) ? tmin_r : __uint_as_float(1u);
                     inv_w = mk(dir.x == 0.0f ? copysignf(3.0e38f, inv_d.x) : inv_d.x, dir.y == 0.0f ? copysignf(3.0e38f, inv_d.y) : inv_d.y,
                                dir.z == 0.0f ? copysignf(3.0e38f, inv_d.z) : inv_d.z);
                     neg_x = inv_w.x < 0.0f; neg_y = inv_w.y < 0.0f; neg_z = inv_w.z < 0.0f;
-                    best.t = tmax_r; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;
-                    best_ci = 0u; best_rank = 0xffffffffu;
-                    reach = tmax_r; runner_up = __builtin_inff();
-                    reach_in = reach * kBeyond;
-                    have_hit = false; again = false;
+                    hits.best.t = e[14 * 64]; hits.best.u = e[15 * 64]; hits.best.v = e[16 * 64]; hits.best.w = e[17 * 64];
+                    hits.best_ci = __float_as_uint(e[18 * 64]); hits.best_rank = __float_as_uint(e[19 * 64]);
+                    hits.reach = e[20 * 64]; hits.runner_up = e[21 * 64];
+                    hits.reach_in = hits.reach * kBeyond;
+                    hits.again = (noted & 0x80000000u) != 0u;
                     w = 0u;
                 } else if (queues_tried >= 8u) {
                     w = kDry;                                      // no stock left and none to come
@@ -1107,6 +1203,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                     atomicAdd(walk_stats + 2, (unsigned long long)n_leaves);
                     atomicAdd(walk_stats + 3, (unsigned long long)n_turns | ((unsigned long long)n_rounds << 32));
                 }
+                if (COUNT && p.walk_hist && lane < 16u) atomicAdd(walk_stats + 4u + lane, (unsigned long long)s_hist[lane]);
                 break;
             }
             continue;
@@ -1118,6 +1215,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
             bool empty_step = false;                       // COUNT: this lane's step found none of the four boxes hit
             if (COUNT) { n_turns += 1u; n_steps += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(w <= kFifo - 1u)); }
             if (w <= kFifo - 1u) {
+                if (COUNT) atomicAdd(&s_hist[min(15u, (31u - (uint32_t)__builtin_clz(h)) >> 1)], 1u);
                 const uint4* rec = reinterpret_cast<const uint4*>(quad_bytes + (h << 6));
                 const uint4 u0 = rec[0], u1 = rec[1], u2 = rec[2];
                 const v2f ix = {inv_w.x, inv_w.x}, iy = {inv_w.y, inv_w.y}, iz = {inv_w.z, inv_w.z};
@@ -1133,10 +1231,10 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                 const float tn1 = vmax3(anx.y, any.y, anz.y), tx1 = vmin3(afx.y, afy.y, afz.y);
                 const float tn2 = vmax3(bnx.x, bny.x, bnz.x), tx2 = vmin3(bfx.x, bfy.x, bfz.x);
                 const float tn3 = vmax3(bnx.y, bny.y, bnz.y), tx3 = vmin3(bfx.y, bfy.y, bfz.y);
-                const bool hit0 = !(tx0 < vmax(tn0, lim)) && (tn0 <= reach_in);
-                const bool hit1 = !(tx1 < vmax(tn1, lim)) && (tn1 <= reach_in);
-                const bool hit2 = !(tx2 < vmax(tn2, lim)) && (tn2 <= reach_in);
-                const bool hit3 = !(tx3 < vmax(tn3, lim)) && (tn3 <= reach_in);
+                const bool hit0 = !(tx0 < vmax(tn0, lim)) && (tn0 <= hits.reach_in);
+                const bool hit1 = !(tx1 < vmax(tn1, lim)) && (tn1 <= hits.reach_in);
+                const bool hit2 = !(tx2 < vmax(tn2, lim)) && (tn2 <= hits.reach_in);
+                const bool hit3 = !(tx3 < vmax(tn3, lim)) && (tn3 <= hits.reach_in);
                 const uint32_t m = (hit0 ? 1u : 0u) | (hit1 ? 2u : 0u) | (hit2 ? 4u : 0u) | (hit3 ? 8u : 0u);
                 if (COUNT) empty_step = m == 0u;
                 if (h < first_leaf_grandparent && m != 0u) {
@@ -1184,7 +1282,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
             if ((w & 15u) != 0u) {
                 // the oldest entry's next leaf; the entry goes when its last leaf is taken or its leaves lie beyond reach
                 const uint2 e = s_fifo[wait_head * 256u];
-                const bool in_reach = __uint_as_float(e.y) <= reach_in;
+                const bool in_reach = __uint_as_float(e.y) <= hits.reach_in;
                 const uint32_t left = e.x >> 28, leaf = (e.x & 0x0fffffffu) + (uint32_t)__builtin_ctz(left);
                 const uint32_t rest = left & (left - 1u);
                 if (rest != 0u && in_reach) {
@@ -1198,41 +1296,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                     const float4* t = reinterpret_cast<const float4*>(leaf_bytes + (size_t)leaf * 128u);      // few per ray: 64-bit offsets cost nothing here
                     const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
                     const float2 places = *reinterpret_cast<const float2*>(t + 5);      // of the two triangles in the reference's order
-                    const uint32_t ci0 = __float_as_uint(l4.z), ci1 = __float_as_uint(l4.w);
-                    Hit h0, h1;
-                    intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
-                    const bool may0 = (tmin_r <= h0.t) && (tmax_r > h0.t) && (h0.t <= reach);
-                    const bool may1 = (ci1 != 0xffffffffu) && (tmin_r <= h1.t) && (tmax_r > h1.t) && (h1.t <= reach);
-                    // few leaves have a triangle that is hit, fewer two: one turn of this loop per such triangle
-#pragma unroll 1
-                    for (uint32_t todo = (may0 ? 1u : 0u) | (may1 ? 2u : 0u); todo != 0u; todo &= todo - 1u) {
-                        {
-                            const bool k = (todo & 1u) == 0u;         // the second triangle's turn
-                            Hit hk;
-                            hk.t = k ? h1.t : h0.t; hk.u = k ? h1.u : h0.u; hk.v = k ? h1.v : h0.v; hk.w = k ? h1.w : h0.w;
-                            const uint32_t ck = k ? ci1 : ci0;
-                            if (hk.t <= reach) {
-                                // The reference tests this triangle only if the box of ITS leaf of the triangle lets
-                                // the ray in: that leaf is the pair of neighbours in the reference's order.
-                                const uint32_t rank = __float_as_uint(k ? places.y : places.x);
-                                const float4* rt = reinterpret_cast<const float4*>(ref_leaf_bytes + (size_t)(rank >> 1) * 128u);
-                                const float entry = leaf_box_entry(org, inv_d, lim, rt[0], rt[1], rt[2], rt[3], rt[4]);
-                                if (entry < __builtin_inff()) {
-                                    const float far_end = fmaxf(entry, hk.t);
-                                    const bool closer = !have_hit || hk.t < best.t || (hk.t == best.t && rank < best_rank);
-                                    if (!closer) {
-                                        runner_up = fminf(runner_up, hk.t);
-                                    } else if (have_hit ? far_end <= reach : far_end < tmax_r) {
-                                        if (have_hit) runner_up = fminf(runner_up, best.t);
-                                        best = hk; best_ci = ck; best_rank = rank; reach = far_end; have_hit = true;
-                                        reach_in = reach * kBeyond;
-                                    } else if (have_hit) {
-                                        again = true;          // a hit that is closer, behind a box entry that is not
-                                    }
-                                }
-                            }
-                        }
-                    }
+                    walk_hits_leaf(hits, org, dir, inv_d, tmin_r, tmax_r, lim, kBeyond, l0, l1, l2, l3, l4, places, ref_leaf_bytes);
                 }
             }
             if (COUNT) n_leaves += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tested));
@@ -1240,12 +1304,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
 
         // 4. a finished ray leaves its closest hit behind and frees the lane
         if (w == kOver) {
-            hit_records[ray] = make_float4(best.t, best.u, best.v, best.w);
-            hit_ci[ray] = best_ci;
-            // the closest hit lies before the entry of its leaf's box and another hit lies in between: which of
-            // them the reference keeps depends on the order it meets them in
-            if (have_hit && reach > best.t && runner_up <= reach) again = true;
-            if (again) flagged[atomicAdd(flag_count, 1u)] = make_uint2(0u, ray);
+            walk_hits_finish(hits, ray, hit_records, hit_ci, flagged, flag_count);
             w = kIdle;
         }
     }
@@ -1487,6 +1546,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         if (accel && accel->num_prims != p.num_prims) return RT_ERR_INVALID_ARGUMENT;
     }
     p.trunk_children = p.lv.count >= 2u ? p.lv.off[p.lv.count - 2u] : 0u;
+    p.walk_hist = 0u;
     ShadeBuffers b;
     b.indices = (const uint32_t*)indices->ptr;
     b.verts = (const rt_vertex*)vertices->ptr;
@@ -1643,12 +1703,14 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         TraceParams ps = p;
         ps.lv = accel->sp_lv;
         ps.trunk_children = ps.lv.count >= 2u ? ps.lv.off[ps.lv.count - 2u] : 0u;
+        ps.walk_hist = dev->walk_stats_hist ? 1u : 0u;
 #define RT_LAUNCH_SPATIAL(COUNT)                                                                                              \
     hipLaunchKernelGGL((k_traverse_spatial<COUNT>), dim3(groups), block,                                                      \
-                       (size_t)(kFifo * 512u + 4u * kStockFields * 64u) * sizeof(uint32_t), s, ps, ray_in,                      \
+                       (size_t)(kFifo * 512u + 4u * kStockFields * 64u + ((COUNT) ? 64u : 0u)) * sizeof(uint32_t), s, ps, ray_in, \
                        (const float4*)accel->sp_nodes, (const float4*)accel->sp_pairs, (const float4*)accel->sp_quads,          \
                        (const float4*)accel->sp_tris, dev->hit_records, dev->hit_ci, dev->queue_counter, order, st,            \
-                       dev->listed_rays, listed, dev->walk_stats, (const uint32_t*)live)
+                       dev->listed_rays, listed, dev->walk_stats, (const uint32_t*)live, (const float4*)accel->outlier_leaves,   \
+                       (const uint32_t*)(accel->cells + RT_CELLS_OUTLIERS))
         if (dev->walk_stats) RT_LAUNCH_SPATIAL(true);
         else RT_LAUNCH_SPATIAL(false);
 #undef RT_LAUNCH_SPATIAL
@@ -1692,6 +1754,7 @@ int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats) {
 int rt_device_set_walk_stats(rt_device* dev, rt_buffer* stats) {
     if (!dev || (stats && stats->bytes < 32u)) return RT_ERR_INVALID_ARGUMENT;
     dev->walk_stats = stats ? (unsigned long long*)stats->ptr : nullptr;
+    dev->walk_stats_hist = stats && stats->bytes >= 160u;      // room for 16 more counters: steps by depth
     return RT_OK;
 }
 
