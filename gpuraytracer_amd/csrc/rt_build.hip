@@ -813,6 +813,54 @@ __device__ __forceinline__ void upsweep_block(Box mine, uint32_t k0, const rt_le
     }
 }
 
+// ---- which triangles share a leaf of the library's own hierarchy ----
+//
+// The walk tests the four leaves under a node two levels above them with one record, so the eight triangles of those four
+// leaf slots may be dealt to the slots in any way: the boxes above stay what they are. Neighbours in the order of the
+// keys make poor pairs - the box around two triangles that merely lie in the same small cell is several times the size of
+// either - so the pairs are chosen by surface area: of the 105 ways to split eight triangles into four pairs, the one whose
+// four boxes have the smallest total surface (what the number of rays that meet a box is proportional to).
+struct PairTable {
+    unsigned char item[105][8];      // matching k: pairs (item[k][0], item[k][1]), (item[k][2], item[k][3]), ...
+    uint32_t code[105];              // the same, three bits per position
+};
+constexpr PairTable make_pair_table() {
+    PairTable t{};
+    int k = 0;
+    // pairs in ascending order of their lowest member, which is always the first of the pair: matching 0 is the identity
+    for (int a = 1; a < 8; a++) {
+        int r6[6] = {0, 0, 0, 0, 0, 0}, n6 = 0;
+        for (int i = 1; i < 8; i++) if (i != a) r6[n6++] = i;
+        for (int b = 1; b < 6; b++) {
+            int r4[4] = {0, 0, 0, 0}, n4 = 0;
+            for (int i = 1; i < 6; i++) if (i != b) r4[n4++] = r6[i];
+            for (int c = 1; c < 4; c++) {
+                int r2[2] = {0, 0}, n2 = 0;
+                for (int i = 1; i < 4; i++) if (i != c) r2[n2++] = r4[i];
+                const int m[8] = {0, a, r6[0], r6[b], r4[0], r4[c], r2[0], r2[1]};
+                uint32_t code = 0u;
+                for (int i = 0; i < 8; i++) { t.item[k][i] = (unsigned char)m[i]; code |= (uint32_t)m[i] << (3 * i); }
+                t.code[k] = code;
+                k++;
+            }
+        }
+    }
+    return t;
+}
+constexpr PairTable kPairs = make_pair_table();
+static_assert(kPairs.code[0] == 0xfac688u, "the first matching keeps every triangle where it is");
+__device__ const uint32_t d_pair_code[105] = {
+#define RT_PC(i) kPairs.code[i]
+#define RT_PC5(i) RT_PC(i), RT_PC(i + 1), RT_PC(i + 2), RT_PC(i + 3), RT_PC(i + 4)
+#define RT_PC15(i) RT_PC5(i), RT_PC5(i + 5), RT_PC5(i + 10)
+    RT_PC15(0), RT_PC15(15), RT_PC15(30), RT_PC15(45), RT_PC15(60), RT_PC15(75), RT_PC15(90)
+#undef RT_PC15
+#undef RT_PC5
+#undef RT_PC
+};
+// index of the pair (a, b), a < b, among the 28
+constexpr int pair_index(int a, int b) { return a * 7 - a * (a - 1) / 2 + (b - a - 1); }
+
 // Leaves (shader/CS_BVHBuildLeaves.hlsl:28-63). PACKED reads the packed pair array and the packed
 // triangles and also emits the Morton-ordered triangle copy; otherwise the reference layout
 // (uint4 records, Indices -> Vertices). FUSED continues with up to eight levels in the same launch.
@@ -835,7 +883,7 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
     __shared__ uint2 s_rank[PACKED ? 256 : 1];
     // the workgroup's 256 leaf records are handed over through LDS so that they leave as runs of whole lines
     // (a lane storing its own record writes 16 bytes to each of 64 different lines per instruction: half the rate)
-    __shared__ float4 s_tri[PACKED ? 256 * 5 : 1];
+    __shared__ float4 s_tri[PACKED ? 256 * 6 : 1];      // (six per lane while the triangles of a group change places)
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t leaves = (num_prims + 1u) / 2u;
     Box b;
@@ -854,21 +902,14 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
         have = 2u * j < count;
         two = 2u * j + 1u < count;
     }
-    if (g < leaves && !have) {                         // an empty slot: a box no ray enters, a triangle no ray hits
-        if (PACKED) {
-            float corner[6][3];
-#pragma unroll
-            for (int i = 0; i < 6; i++) corner[i][0] = corner[i][1] = corner[i][2] = 0.0f;
-            leaf_triangle_record(s_tri + 5u * threadIdx.x, corner, ci0, ci1);
-        }
-        store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
-    }
     uint32_t place0 = 0u, place1 = 0xffffffffu;        // with ref_leaves: the triangles' places in the reference's order
+    float corner[6][3];
+#pragma unroll
+    for (int i = 0; i < 6; i++) corner[i][0] = corner[i][1] = corner[i][2] = 0.0f;
     if (have) {
         constexpr int STRIDE = PACKED ? 2 : 4;
         ci0 = sorted[(size_t)r0 * STRIDE + 1];
         if (two) ci1 = sorted[(size_t)(r0 + 1u) * STRIDE + 1];
-        float corner[6][3];
         if (PACKED && ref_leaves) {
             place0 = ci0; place1 = two ? ci1 : 0xffffffffu;
             // one half of an interleaved record (leaf_triangle_record): corners into corner[K .. K + 2], index slot into CI
@@ -900,6 +941,85 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
                 }
             }
         }
+    }
+    if (PACKED && ref_leaves && cells && slots_log2 - cells[0] >= 2u) {       // same for the whole grid
+        // The library's own hierarchy: the eight triangles of four neighbouring leaf slots (one record of the walk) are
+        // paired anew by surface area (see PairTable). The lanes of the four slots hand their triangles over through LDS,
+        // each works out the best matching of the eight, and takes the two triangles of its place in it.
+        // A group's triangles fill its places from the front; the last one of an odd number stays alone where it is.
+        float4* mine = s_tri + 6u * threadIdx.x;
+        mine[0] = make_float4(corner[0][0], corner[0][1], corner[0][2], __uint_as_float(ci0));
+        mine[1] = make_float4(corner[1][0], corner[1][1], corner[1][2], __uint_as_float(place0));
+        mine[2] = make_float4(corner[2][0], corner[2][1], corner[2][2], 0.0f);
+        mine[3] = make_float4(corner[3][0], corner[3][1], corner[3][2], __uint_as_float(ci1));
+        mine[4] = make_float4(corner[4][0], corner[4][1], corner[4][2], __uint_as_float(place1));
+        mine[5] = make_float4(corner[5][0], corner[5][1], corner[5][2], 0.0f);
+        const unsigned long long first_mask = __builtin_amdgcn_ballot_w64(have), second_mask = __builtin_amdgcn_ballot_w64(have && two);
+        const uint32_t quad = threadIdx.x & 60u;
+        const uint32_t there = (uint32_t)__popcll((first_mask >> quad) & 15ull) + (uint32_t)__popcll((second_mask >> quad) & 15ull);
+        const uint32_t paired = there & ~1u;           // triangles that take part
+        __syncthreads();
+        uint32_t code = kPairs.code[0];
+        if (paired >= 4u) {
+            const float4* group = s_tri + 6u * (threadIdx.x & ~3u);
+            float area[28];
+            {
+                float mn[8][3], mx[8][3];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float4 a = group[3 * i], b2 = group[3 * i + 1], c = group[3 * i + 2];
+                    mn[i][0] = fminf(fminf(a.x, b2.x), c.x); mn[i][1] = fminf(fminf(a.y, b2.y), c.y); mn[i][2] = fminf(fminf(a.z, b2.z), c.z);
+                    mx[i][0] = fmaxf(fmaxf(a.x, b2.x), c.x); mx[i][1] = fmaxf(fmaxf(a.y, b2.y), c.y); mx[i][2] = fmaxf(fmaxf(a.z, b2.z), c.z);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+#pragma unroll
+                    for (int j = i + 1; j < 8; j++) {
+                        const float ex = fmaxf(mx[i][0], mx[j][0]) - fminf(mn[i][0], mn[j][0]);
+                        const float ey = fmaxf(mx[i][1], mx[j][1]) - fminf(mn[i][1], mn[j][1]);
+                        const float ez = fmaxf(mx[i][2], mx[j][2]) - fminf(mn[i][2], mn[j][2]);
+                        // a pair of triangles that take part costs its box's surface; pairs of the others cost nothing, so
+                        // that they stay together behind; mixed pairs are out
+                        area[pair_index(i, j)] = (uint32_t)j < paired ? (ex * ey + ey * ez) + ez * ex
+                                                                      : ((uint32_t)i < paired ? __builtin_inff() : 0.0f);
+                    }
+            }
+            float best = __builtin_inff();
+            uint32_t best_k = 0u;
+#pragma unroll
+            for (int k = 0; k < 105; k++) {
+                const float cost = (area[pair_index(kPairs.item[k][0], kPairs.item[k][1])] + area[pair_index(kPairs.item[k][2], kPairs.item[k][3])]) +
+                                   (area[pair_index(kPairs.item[k][4], kPairs.item[k][5])] + area[pair_index(kPairs.item[k][6], kPairs.item[k][7])]);
+                if (cost < best) { best = cost; best_k = (uint32_t)k; }
+            }
+            code = d_pair_code[best_k];
+        }
+        if (have) {
+            const uint32_t at = 2u * (threadIdx.x & 3u);
+            const float4* t0 = s_tri + 6u * (threadIdx.x & ~3u) + 3u * ((code >> (3u * at)) & 7u);
+            const float4* t1 = s_tri + 6u * (threadIdx.x & ~3u) + 3u * ((code >> (3u * at + 3u)) & 7u);
+            const float4 a0 = t0[0], b0 = t0[1], c0 = t0[2], a1 = t1[0], b1 = t1[1], c1 = t1[2];
+            corner[0][0] = a0.x; corner[0][1] = a0.y; corner[0][2] = a0.z; ci0 = __float_as_uint(a0.w);
+            corner[1][0] = b0.x; corner[1][1] = b0.y; corner[1][2] = b0.z; place0 = __float_as_uint(b0.w);
+            corner[2][0] = c0.x; corner[2][1] = c0.y; corner[2][2] = c0.z;
+            if (two) {
+                corner[3][0] = a1.x; corner[3][1] = a1.y; corner[3][2] = a1.z; ci1 = __float_as_uint(a1.w);
+                corner[4][0] = b1.x; corner[4][1] = b1.y; corner[4][2] = b1.z; place1 = __float_as_uint(b1.w);
+                corner[5][0] = c1.x; corner[5][1] = c1.y; corner[5][2] = c1.z;
+            }
+        }
+        __syncthreads();                               // the leaf records below go to the same LDS
+    }
+    if (g < leaves && !have) {                         // an empty slot: a box no ray enters, a triangle no ray hits
+        if (PACKED) {
+            float none[6][3];
+#pragma unroll
+            for (int i = 0; i < 6; i++) none[i][0] = none[i][1] = none[i][2] = 0.0f;
+            leaf_triangle_record(s_tri + 5u * threadIdx.x, none, ci0, ci1);
+        }
+        store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
+    }
+    if (have) {
         if (!two) {                                     // no second triangle: repeat the first
 #pragma unroll
             for (int i = 0; i < 3; i++) { corner[3 + i][0] = corner[i][0]; corner[3 + i][1] = corner[i][1]; corner[3 + i][2] = corner[i][2]; }
