@@ -1,4 +1,4 @@
-"""ctypes binding of the gpurt C-ABI (include/gpurt.h).
+"""ctypes binding of the gpurt C-ABI (include/gpurt.h, and the instrumentation of include/gpurt_debug.h).
 
 The library is the product; this module only loads it and declares its entry points. There
 is no CPU fallback: importing succeeds without the shared object (so that CPU-only tooling
@@ -91,7 +91,7 @@ _P = C.c_void_p
 _U32 = C.c_uint32
 _SZ = C.c_size_t
 
-# name -> (restype, argtypes); exactly the symbols include/gpurt.h declares
+# name -> (restype, argtypes); exactly the symbols include/gpurt.h and include/gpurt_debug.h declare
 SIGNATURES = {
     "rt_device_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "rt_device_destroy": (C.c_int, [_P]),
@@ -138,6 +138,7 @@ SIGNATURES = {
     "rt_device_set_trace_tuning": (C.c_int, [_P, C.POINTER(TraceTuning)]),
     "rt_accel_set_second_hierarchy": (C.c_int, [_P, C.c_int, _U32]),
     "rt_device_set_walk_stats": (C.c_int, [_P, _P]),
+    "rt_accel_outliers": (C.c_int, [_P, C.POINTER(_U32), C.POINTER(_U32)]),
     "rt_scene_bounds": (C.c_int, [_P, _U32, _P, _P, _P]),
     "rt_scene_bounds_static": (C.c_int, [_P, _U32, _P, _P, _P]),
     "rt_accel_pack_bounds": (C.c_int, [_P, _U32, _P, _P, _P]),

@@ -301,47 +301,50 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
     for (int d = 1; d < 64; d <<= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
     return v;
 }
-// With F = RT_CELL_BITS_MAX: fullest cell at T = F, F - 3 and F - 6, and the counts of the cells of T = F - 6; one thread
-// per finest cell
-constexpr uint32_t kCoarse = 1u << (RT_CELL_BITS_MAX - 6u);        // cells of the level one wave sums up
-__global__ __launch_bounds__(256) void k_cell_sums(uint32_t* __restrict__ cells) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+// With F = RT_CELL_BITS_MAX: a workgroup of 512 sums the counts of 512 finest cells, i.e. one cell of F - 9 bits, and
+// leaves that count and the fullest cell it has seen at T = F, F - 3 and F - 6; one thread per finest cell
+constexpr uint32_t kCoarse = 1u << (RT_CELL_BITS_MAX - 9u);        // cells of the level one workgroup sums up
+__global__ __launch_bounds__(512) void k_cell_sums(uint32_t* __restrict__ cells) {
+    __shared__ uint32_t s_part[8][3];
+    const uint32_t i = blockIdx.x * 512u + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t v = cells[RT_CELLS_HIST + i];
     const uint32_t m0 = wave_max(v);
     v += (uint32_t)__shfl_xor((int)v, 1, 64); v += (uint32_t)__shfl_xor((int)v, 2, 64); v += (uint32_t)__shfl_xor((int)v, 4, 64);
     const uint32_t m1 = wave_max(v);
     v += (uint32_t)__shfl_xor((int)v, 8, 64); v += (uint32_t)__shfl_xor((int)v, 16, 64); v += (uint32_t)__shfl_xor((int)v, 32, 64);
-    if (lane == 0u) {
-        // the wave's maxima go to the (still unused) table of cell starts; k_cell_choose gathers them: thousands of
+    if (lane == 0u) { s_part[wave][0] = m0; s_part[wave][1] = m1; s_part[wave][2] = v; }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t a0 = 0u, a1 = 0u, a2 = 0u, sum = 0u;
+        for (int w = 0; w < 8; w++) { a0 = max(a0, s_part[w][0]); a1 = max(a1, s_part[w][1]); a2 = max(a2, s_part[w][2]); sum += s_part[w][2]; }
+        // the maxima go to the (still unused) table of cell starts; k_cell_choose gathers them: thousands of
         // atomics on three words would take longer than the rest of the build's bookkeeping together
-        cells[RT_CELLS_HIST12 + (i >> 6)] = v;
-        cells[RT_CELLS_START + (i >> 6)] = m0;
-        cells[RT_CELLS_START + kCoarse + (i >> 6)] = m1;
+        cells[RT_CELLS_HIST12 + blockIdx.x] = sum;
+        cells[RT_CELLS_HIST12 + kCoarse + blockIdx.x] = a2;
+        cells[RT_CELLS_START + blockIdx.x] = a0;
+        cells[RT_CELLS_START + kCoarse + blockIdx.x] = a1;
     }
 }
 // fullest cells of the coarser levels (each the sum of eight of the level below), and the choice of T; one workgroup
 // of 1024
 __global__ __launch_bounds__(1024) void k_cell_choose(uint32_t* __restrict__ cells, uint32_t slots_log2, uint32_t t_cap) {
-    static_assert(RT_CELL_BITS_MAX == 21u, "the sums below go 15 -> 12 -> 9 -> 6 -> 3 bits");
+    static_assert(RT_CELL_BITS_MAX == 21u && kCoarse == 4096u, "the sums below go 12 -> 9 -> 6 -> 3 bits");
     __shared__ uint32_t s12[4096], s9[512], s6[64], s3[8], s_max[7];
     const uint32_t t = threadIdx.x;
     if (t < 7u) s_max[t] = 0u;
     __syncthreads();
-    {   // fullest cells of T = 21, 18, 15 from the per-wave values of k_cell_sums
-        uint32_t m0 = 0u, m1 = 0u, m2 = 0u;
+    {   // fullest cells of T = 21, 18, 15, 12 from the per-workgroup values of k_cell_sums
+        uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
         for (uint32_t j = t; j < kCoarse; j += 1024u) {
             m0 = max(m0, cells[RT_CELLS_START + j]);
             m1 = max(m1, cells[RT_CELLS_START + kCoarse + j]);
-            m2 = max(m2, cells[RT_CELLS_HIST12 + j]);
+            m2 = max(m2, cells[RT_CELLS_HIST12 + kCoarse + j]);
+            const uint32_t c = cells[RT_CELLS_HIST12 + j];
+            s12[j] = c;
+            m3 = max(m3, c);
         }
-        m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2);
-        if ((t & 63u) == 0u) { atomicMax(&s_max[0], m0); atomicMax(&s_max[1], m1); atomicMax(&s_max[2], m2); }
-    }
-    for (uint32_t c = t; c < 4096u; c += 1024u) {
-        uint32_t v = 0u;
-        for (uint32_t j = 0; j < 8u; j++) v += cells[RT_CELLS_HIST12 + 8u * c + j];
-        s12[c] = v;
-        atomicMax(&s_max[3], v);
+        m0 = wave_max(m0); m1 = wave_max(m1); m2 = wave_max(m2); m3 = wave_max(m3);
+        if ((t & 63u) == 0u) { atomicMax(&s_max[0], m0); atomicMax(&s_max[1], m1); atomicMax(&s_max[2], m2); atomicMax(&s_max[3], m3); }
     }
     __syncthreads();
     if (t < 512u) { uint32_t v = 0u; for (uint32_t j = 0; j < 8u; j++) v += s12[8u * t + j]; s9[t] = v; atomicMax(&s_max[4], v); }
@@ -1307,7 +1310,8 @@ int rt_accel_pairs(rt_accel* a, bool own, const rt_aabb* nodes, const float4** p
     return rt_launch_status();
 }
 
-int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted, bool first_counted) {
+int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted, bool first_counted,
+                  uint32_t first_shift) {
     int rc = rt_sort_workspace(dev, n);
     if (rc) return rc;
     hipStream_t s = dev->stream;
@@ -1315,7 +1319,7 @@ int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passe
     uint2* src = a;
     uint2* dst = b;
     for (uint32_t pass = 0; pass < passes; pass++) {
-        const uint32_t shift = 8u * pass;
+        const uint32_t shift = first_shift + 8u * pass;
         // (first_counted: the kernel that made the keys has left the first pass's per-tile counts in the table)
         if (pass || !first_counted)
             hipLaunchKernelGGL((k_sort_hist<2, false>), dim3(tiles), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)nullptr, n,
@@ -1530,6 +1534,18 @@ int rt_accel_set_second_hierarchy(rt_accel* a, int enable, uint32_t cell_bits) {
     return RT_OK;
 }
 
+int rt_accel_outliers(rt_accel* a, uint32_t* found, uint32_t* listed) {
+    if (!a || !found || !listed) return RT_ERR_INVALID_ARGUMENT;
+    *found = *listed = 0u;
+    if (!a->sp_built) return RT_OK;                  // the last build made no second hierarchy, hence no list
+    int rc = rt_set_device(a->dev);
+    if (rc) return rc;
+    RT_HIP(hipMemcpyAsync(found, a->cells + RT_CELLS_OUTLIERS, sizeof(uint32_t), hipMemcpyDeviceToHost, a->dev->stream));
+    RT_HIP(hipStreamSynchronize(a->dev->stream));
+    *listed = *found < RT_OUTLIERS_MAX ? *found : RT_OUTLIERS_MAX;
+    return RT_OK;
+}
+
 int rt_accel_pack(rt_accel* a, uint32_t num_primitives, const rt_buffer* indices, const rt_buffer* vertices) {
     if (!a || !indices || !vertices) return RT_ERR_INVALID_ARGUMENT;
     if (num_primitives < 3u) return RT_ERR_TOO_FEW_PRIMITIVES;
@@ -1709,7 +1725,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
         // (the per-axis histograms and, right behind them, the count of outliers)
         static_assert(RT_CELLS_OUTLIERS == RT_CELLS_AXIS + 3u * RT_AXIS_STEPS, "one memset clears both");
         RT_HIP(hipMemsetAsync(a->cells + RT_CELLS_AXIS, 0, (size_t)(3u * RT_AXIS_STEPS + 1u) * sizeof(uint32_t), s));
-        const uint32_t stride = n > (1u << 18) ? (n >> 18) + 1u : 1u;         // a quarter of a million samples are plenty for 4096 steps
+        const uint32_t stride = n > (1u << 16) ? (n >> 16) + 1u : 1u;         // 65 536 samples: 64 per step of the 1024 coordinates made
         const uint32_t samples = div_up(n, stride);
         hipLaunchKernelGGL(k_axis_hist, dim3(min(div_up(samples, 256u), 512u)), dim3(256), 0, s, spb, dbounds, n, stride, a->tris, a->cells);
         hipLaunchKernelGGL(k_axis_map, dim3(3), dim3(1024), 0, s, samples, a->cells);
@@ -1737,7 +1753,9 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     if (!own) return rt_launch_status();
     // (key, place in the reference's order) of every triangle, written by the leaf kernel above, sorted by key
     uint2* sp_src = nullptr;
-    rc = rt_sort_pairs(dev, other, src, n, 4u, &sp_src);
+    // (by the upper 24 of the key's 32 bits: the lowest eight tell triangles apart that share a cell of 2^-22 of the
+    // curve, far below the cells the leaf slots are laid out by, and the pairing inside a record looks at the boxes anyway)
+    rc = rt_sort_pairs(dev, other, src, n, 3u, &sp_src, false, 8u);
     if (rc) return rc;
     a->sp_sorted = sp_src;
     // leaf slots by Morton cell where the cells fit (k_cell_choose), then leaves and levels over all the slots
@@ -1748,7 +1766,7 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     const rt_levels& sl = a->sp_lv;
     RT_HIP(hipMemsetAsync(a->cells, 0, (size_t)RT_CELLS_START * sizeof(uint32_t), s));
     hipLaunchKernelGGL(k_cell_hist, dim3(div_up(n, 256u)), dim3(256), 0, s, n, (const uint2*)sp_src, a->cells);
-    hipLaunchKernelGGL(k_cell_sums, dim3((1u << RT_CELL_BITS_MAX) / 256u), dim3(256), 0, s, a->cells);
+    hipLaunchKernelGGL(k_cell_sums, dim3((1u << RT_CELL_BITS_MAX) / 512u), dim3(512), 0, s, a->cells);
     hipLaunchKernelGGL(k_cell_choose, dim3(1), dim3(1024), 0, s, a->cells, slots_log2, a->cell_bits_cap);
     hipLaunchKernelGGL(k_cell_starts, dim3(div_up(n, 256u)), dim3(256), 0, s, n, (const uint2*)sp_src, a->cells);
     hipLaunchKernelGGL(k_cell_fill, dim3(256), dim3(256), 0, s, a->cells);

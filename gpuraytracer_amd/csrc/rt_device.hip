@@ -66,7 +66,7 @@ int rt_device_create(int gpu_index, rt_device** out) {
         t.leaf_threshold = env("GPURT_LEAF_THRESHOLD", 0u);
         t.refill_threshold = env("GPURT_REFILL_THRESHOLD", 0u);
         t.blocks_per_cu = env("GPURT_BLOCKS_PER_CU", 4u);
-        t.sort_rays = env("GPURT_SORT_RAYS", 1u);
+        t.sort_rays = env("GPURT_SORT_RAYS", 2u);
         t.deal_shift = env("GPURT_DEAL_SHIFT", 6u);
         t.cost_bits = env("GPURT_COST_BITS", 6u);
         t.cost_depth = env("GPURT_COST_DEPTH", 0u);

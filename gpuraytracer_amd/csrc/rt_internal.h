@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "gpurt.h"
+#include "gpurt_debug.h"
 
 struct rt_device {
     int gpu;
@@ -85,7 +86,7 @@ static inline rt_trace_tuning rt_clamp_tuning(rt_trace_tuning t) {
     if (t.refill_threshold > 64u) t.refill_threshold = 64u;
     if (t.blocks_per_cu < 1u) t.blocks_per_cu = 1u;
     if (t.blocks_per_cu > 8u) t.blocks_per_cu = 8u;
-    t.sort_rays = t.sort_rays ? 1u : 0u;
+    if (t.sort_rays > 2u) t.sort_rays = 1u;
     if (t.deal_shift < 6u) t.deal_shift = 6u;
     if (t.deal_shift > 20u) t.deal_shift = 20u;
     if (t.cost_bits < 6u) t.cost_bits = 6u;
@@ -122,7 +123,9 @@ int rt_static_scratch_init(int gpu);
 const char* rt_comm_error_string(int code);
 // Stable LSD radix sort of (key, value) pairs by the low 8 * passes key bits, queued on the device's stream.
 // a and b hold n pairs each and are both overwritten; *sorted receives whichever of them holds the result.
-int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted, bool first_counted = false);
+// first_shift: the lowest key bit that counts.
+int rt_sort_pairs(rt_device* dev, uint2* a, uint2* b, uint32_t n, uint32_t passes, uint2** sorted, bool first_counted = false,
+                  uint32_t first_shift = 0u);
 // Writes the private copy (interleaved sibling pairs, Morton-ordered packed triangles: see rt_levels and
 // rt_accel) of a hierarchy held in the reference's layout. pairs: rt_aligned_node_slots() slots;
 // sorted_tris: 5 float4 per leaf.
@@ -222,7 +225,7 @@ struct rt_accel {
 // rt_accel::cells, in uint32 (everything before RT_CELLS_START is cleared by every build): [0..7] layout {cell bits T, largest cell at T = 21, 18, ... 3}; then the triangles per cell
 // of the finest level, the cells of 15 bits summed from them, and the first rank of every cell at the chosen level
 constexpr uint32_t RT_CELLS_HIST = 8u;
-constexpr uint32_t RT_CELLS_HIST12 = RT_CELLS_HIST + (1u << RT_CELL_BITS_MAX);          // cells of RT_CELL_BITS_MAX - 6 bits
+constexpr uint32_t RT_CELLS_HIST12 = RT_CELLS_HIST + (1u << RT_CELL_BITS_MAX);          // cells of RT_CELL_BITS_MAX - 9 bits, then the fullest cells of - 6 bits
 constexpr uint32_t RT_CELLS_START = RT_CELLS_HIST12 + (1u << (RT_CELL_BITS_MAX - 6u));
 // ... and, per axis, how many centroids fall into each of 4096 equal steps of the scene bounds, turned into the
 // 10-bit coordinate the keys are made of (k_axis_map)

@@ -193,10 +193,10 @@ __device__ __forceinline__ void shade_ray(const TraceParams& p, const ShadeBuffe
     const uint32_t off = __float_as_uint(o1.w);
     const uint32_t idx = local_ray(p, ((uint32_t)p.width * py + px) * p.rpp + off);
     // pixel data that does not belong to these rows: an out-of-range structured-buffer access of the reference reads
-    // zeros and drops the write; here the ray is left alone
-    if (idx >= p.num_rays) return;
-    float4 S = b.scattered[idx];
-    float4 E = b.emitted[idx];
+    // zeros and drops the write (the ray itself is scattered all the same)
+    const bool lit = idx < p.num_rays;
+    float4 S = make_float4(0.0f, 0.0f, 0.0f, 0.0f), E = S;
+    if (lit) { S = b.scattered[idx]; E = b.emitted[idx]; }
 
     if (best.t != tmax_r) {
         const uint32_t ia = b.indices[best_ci], ib = b.indices[best_ci + 1], ic = b.indices[best_ci + 2];
@@ -270,8 +270,10 @@ __device__ __forceinline__ void shade_ray(const TraceParams& p, const ShadeBuffe
         b.old_rays[2 * (size_t)tid] = r0;
         b.old_rays[2 * (size_t)tid + 1] = make_float4(r1.x, r1.y, r1.z, o1.w);
     }
-    b.scattered[idx] = S;
-    b.emitted[idx] = E;
+    if (lit) {
+        b.scattered[idx] = S;
+        b.emitted[idx] = E;
+    }
 }
 
 // sums four per-thread counters over the workgroup's present lanes into stats[0..3]
@@ -1515,7 +1517,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     // leaves and does better with fuller rounds)
     const uint32_t leaf_threshold = tune.leaf_threshold ? tune.leaf_threshold : (spatial_kernel ? 32u : 16u);
     const uint32_t blocks_per_cu = tune.blocks_per_cu;
-    const uint32_t sort_rays = tune.sort_rays;
+    const uint32_t sort_rays = tune.sort_rays == 2u ? ((spatial_kernel && !dev->drop_missed && !stats) ? 0u : 1u) : tune.sort_rays;
     dev->listed_valid = false;
 
     TraceParams p;

@@ -84,10 +84,6 @@ int rt_device_set_stream(rt_device* dev, void* hip_stream); /* adopt a caller-ow
 int rt_device_index(rt_device* dev);
 const char* rt_error_string(int code);
 
-/* Instrumentation (no counterpart in the reference): while a 32-byte buffer is set, every trace launch adds
- * {box tests, triangle tests, rays that hit, rays} as four uint64 to it (a slower kernel variant); NULL turns
- * it off. The counts fix the algorithmic bytes per ray of a workload. */
-int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats);
 /* Which traversal kernel rt_trace_rays / rt_trace_rays_accel launch (no counterpart in the reference).
  * QUAD, WAVE and SIMPLE walk the reference's hierarchy in the reference's order and return the reference's closest
  * hit by construction: QUAD two levels per step on 64-byte records, WAVE one level per step (also used for
@@ -98,8 +94,10 @@ int rt_device_set_trace_stats(rt_device* dev, rt_buffer* stats);
  * numerically false: a near-degenerate triangle whose hit test accepts a ray that passes beside the triangle's own
  * (slightly widened) box, or far enough in front of it - see the kernel's description; comparisons of the two walks
  * over random scenes put that below one ray in 10^9. Whether rt_accel_build makes the second hierarchy is a property of
- * the accel (rt_accel_set_second_hierarchy, on by default); an accel built without it is traced by QUAD. The
- * environment variable GPURT_TRACE_KERNEL = spatial | quad | wave | simple sets the initial choice of a new device. */
+ * the accel (rt_accel_set_second_hierarchy, on by default); an accel built without it is traced by QUAD. Triangles whose
+ * box is a large part of the scene's (walls, a floor: up to 64 per build) are left out of that second hierarchy, in which
+ * they would make every node above them as large as themselves, and are tested from a list before a ray's walk starts.
+ * Instrumentation and test-only switches of these kernels are declared in gpurt_debug.h. The environment variable GPURT_TRACE_KERNEL = spatial | quad | wave | simple sets the initial choice of a new device. */
 #define RT_TRACE_KERNEL_QUAD 0
 #define RT_TRACE_KERNEL_WAVE 1
 #define RT_TRACE_KERNEL_SIMPLE 2
@@ -127,7 +125,10 @@ typedef struct {
     uint32_t leaf_threshold;    /* GPURT_LEAF_THRESHOLD: lanes with a leaf waiting that start a triangle round; 0 = 32 (SPATIAL) / 16 */
     uint32_t refill_threshold;  /* GPURT_REFILL_THRESHOLD: free lanes that start a refill; 0 = 8 (SPATIAL) / 16 */
     uint32_t blocks_per_cu;     /* GPURT_BLOCKS_PER_CU: persistent workgroups per compute unit; default 4 */
-    uint32_t sort_rays;         /* GPURT_SORT_RAYS: 1 = order the rays of a launch by estimated walk length, 0 = as they come */
+    uint32_t sort_rays;         /* GPURT_SORT_RAYS: 1 = order the rays of a launch by estimated walk length, 0 = as they come,
+                                   2 (default) = order them for the walks in the reference's order and where missed rays are
+                                   dropped, not for the default kernel (its walks are short and alike: measured, the order
+                                   costs what it gains) */
     uint32_t deal_shift;        /* GPURT_DEAL_SHIFT: log2 of the block of ray-order positions dealt to one queue; 6 .. 20, default 6 */
     uint32_t cost_bits;         /* GPURT_COST_BITS: bits of the walk-length class in the ray key; 6 .. 12, default 6 */
     uint32_t cost_depth;        /* GPURT_COST_DEPTH: tree depth probed for the walk-length estimate; 0 = default (no probe on SPATIAL) */
@@ -135,29 +136,8 @@ typedef struct {
     uint32_t cost_chord;        /* GPURT_COST_CHORD: 1 = estimate from the ray's way through the trunk's box, 0 = probe, 2 = default */
     uint32_t key_passes;        /* GPURT_KEY_PASSES: 8-bit sorting passes over the ray keys, 1 .. 3; 0 = default */
 } rt_trace_tuning;
-/* Diagnostics (no counterpart in the reference): the two safety margins of the SPATIAL kernel. entry_margin: boxes are
- * entered up to reach * entry_margin (default 1 + 2^-8; 1 = no margin); sliver_pad: own leaf boxes of triangles whose
- * altitude is below 1/64 of their longest edge are widened by sliver_pad * that edge on every side at the next build
- * (default 1/32; 0 = no room). Smaller values make the kernel miss hits the reference finds - they exist so that tests
- * can show what the margins are for. Values outside [1, 2] and [0, 1] are refused. */
-int rt_device_set_walk_margins(rt_device* dev, float entry_margin, float sliver_pad);
 int rt_device_get_trace_tuning(rt_device* dev, rt_trace_tuning* out);
 int rt_device_set_trace_tuning(rt_device* dev, const rt_trace_tuning* tuning);   /* out-of-range values are clamped */
-/* Instrumentation (no counterpart in the reference): how many rays of the device's last trace call the SPATIAL
- * kernel handed to the walk in the reference's order (0 after a call with another kernel). Waits for the stream. */
-int rt_device_listed_rays(rt_device* dev, uint32_t* count);
-/* Instrumentation (no counterpart in the reference): while a 32-byte buffer is set, every launch of the SPATIAL kernel
- * adds {steps (one 64-byte record read and four boxes tested each), steps that hit none of the four, leaves whose
- * triangles were tested, turns of the waves' walking loops | triangle rounds of the waves << 32} as four uint64 to
- * it; NULL turns it off. The kernel's own algorithmic bytes come from the first three; steps / (64 * turns) and
- * leaves / (64 * rounds) are the shares of a wave's 64 lanes at work in a walking turn and in a triangle round
- * (the two halves of the fourth word hold 2^32 each: clear the buffer before they fill). */
-int rt_device_set_walk_stats(rt_device* dev, rt_buffer* stats);
-/* Instrumentation (no counterpart in the reference): while enabled, every trace launch brackets its traversal
- * kernel with a pair of events on the device's stream. rt_device_traverse_timing waits for the pairs recorded
- * so far, returns the sum of their durations and their number, and forgets them. */
-int rt_device_set_traverse_timing(rt_device* dev, int enable);
-int rt_device_traverse_timing(rt_device* dev, double* total_ms, uint32_t* launches);
 
 int rt_event_create(rt_device* dev, rt_event** out);
 int rt_event_record(rt_event* ev);                       /* on the device's stream */

@@ -1,9 +1,16 @@
 #!/bin/bash
-# Sweep of one GPURT_* variable on one workload (GPU box): bash scripts/tuning_sweep.sh <workload> <VARIABLE> <values...>
-set -u
-WL=$1; VAR=$2; shift 2
-for v in "$@"; do
-  env "$VAR=$v" timeout -k 10 300 python bench.py --workload "$WL" --steps 3 --warmup 1 --no-cpu-baseline --no-counters --no-reference-walk > gpurun_out/sweep.json 2> gpurun_out/sweep.err || { tail -3 gpurun_out/sweep.err; exit 1; }
-  python -c "
-import json; d=json.load(open('gpurun_out/sweep.json')); print('$WL $VAR=$v: %.1f Mrays/s, launch %.4f ms, trace call %.4f ms' % (d['value'], d['roofline']['avg_launch_ms'], d['roofline']['avg_trace_call_ms']))"
-done
+# Mrays/s of the default kernel over its tuning knobs (C3): bash scripts/tuning_sweep.sh
+out=gpurun_out/tuning_sweep.txt
+: > $out
+run() {
+  echo "== $*" >> $out
+  env "$@" timeout -k 10 150 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-counters --no-reference-walk \
+    | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print(d['value'], r['avg_launch_ms'], d['trace_ms_by_bounce'])" >> $out || exit 1
+}
+for t in 16 24 32 40 48; do run GPURT_LEAF_THRESHOLD=$t; done
+for t in 4 12 16 24; do run GPURT_REFILL_THRESHOLD=$t; done
+for t in 3 5; do run GPURT_BLOCKS_PER_CU=$t; done
+run GPURT_KEY_PASSES=1
+run GPURT_KEY_PASSES=3
+run GPURT_SORT_RAYS=0
+cat $out

@@ -348,7 +348,8 @@ def test_every_tuning_knob_keeps_the_oracle_image(device, oracle):
     capi.check(device.lib.rt_device_get_trace_tuning(device.handle, C.byref(base)), "rt_device_get_trace_tuning")
     knobs = dict(leaf_threshold=5, refill_threshold=40, blocks_per_cu=2, sort_rays=0, deal_shift=9, cost_bits=9, cost_depth=7,
                  cost_stride=3, cost_chord=0, key_passes=1)
-    cases = [{k: v} for k, v in knobs.items()] + [dict(knobs), dict(cost_chord=1, key_passes=3), dict(leaf_threshold=64, refill_threshold=1)]
+    cases = [{k: v} for k, v in knobs.items()] + [dict(knobs), dict(cost_chord=1, key_passes=3), dict(leaf_threshold=64, refill_threshold=1),
+                                                            dict(sort_rays=1), dict(sort_rays=2)]
     for case in cases:
         t = capi.TraceTuning()
         C.memmove(C.byref(t), C.byref(base), C.sizeof(t))

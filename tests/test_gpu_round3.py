@@ -1,0 +1,165 @@
+"""GPU tests of what the default traversal kernel leaves out of its own hierarchy (outliers: triangles whose box is
+a large part of the scene's), of pixel data that belongs to another device's rows, and of the full-size
+configurations as far as they were open: every comparison is bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KERNEL_QUAD, KERNEL_WAVE, KERNEL_SIMPLE, KERNEL_SPATIAL = 0, 1, 2, 3
+
+
+def _scene_of(pos, name, camera=None):
+    """A scene from triangle corners pos[n, 3, 3]: eight materials in turn, one of them a light."""
+    from gpuraytracer_amd import scenes
+    from gpuraytracer_amd.capi import vertex_dtype
+    pos = np.asarray(pos, dtype=np.float32)
+    n = pos.shape[0]
+    v = np.zeros(3 * n, dtype=vertex_dtype)
+    v["position"] = pos.reshape(-1, 3)
+    d1, d2 = pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]
+    nrm = np.cross(d1, d2).astype(np.float32)
+    ln = np.sqrt((nrm * nrm).sum(axis=1, dtype=np.float32)).astype(np.float32)
+    nrm = (nrm / np.where(ln == 0, np.float32(1), ln)[:, None]).astype(np.float32)
+    v["normal"] = np.repeat(nrm, 3, axis=0)
+    v["uv"] = np.tile(np.array([[0, 0], [1, 0], [0, 1]], dtype=np.float32), (n, 1))
+    v["material_id"] = np.repeat(np.arange(n, dtype=np.uint32) % np.uint32(8), 3)
+    idx = np.arange(3 * n, dtype=np.uint32)
+    atlas, ids = scenes.default_atlas()
+    smin, smax = scenes.centroid_bounds(v, idx)
+    cam = camera or dict(position=(0.0, 0.0, -22.0), focus=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=1.2, near_z=0.01, far_z=10000.0)
+    return dict(vertices=v, indices=idx, materials=scenes.synthetic_materials(), texture_ids=ids, atlas=atlas, scene_min=smin,
+                scene_max=smax, camera=cam, name=name)
+
+
+def _soup(n, rng, half=10.0, edge=None):
+    e = edge if edge is not None else 20.0 / np.cbrt(n)
+    c = rng.uniform(-half, half, (n, 1, 3))
+    p = c + np.concatenate([np.zeros((n, 1, 3)), rng.uniform(-e, e, (n, 2, 3))], axis=1)
+    return p.astype(np.float32)
+
+
+def _sheets(k, rng, half=25.0):
+    """k large triangles: random planes through the scene, each several times the size of the soup."""
+    c = rng.uniform(-0.5 * half, 0.5 * half, (k, 1, 3))
+    return (c + rng.uniform(-half, half, (k, 3, 3))).astype(np.float32)
+
+
+def _render(device, oracle, sc, w, h, cycles, depth, kernel, **kw):
+    from tests.test_gpu_round2 import ALL, _gpu_render
+    return _gpu_render(device, oracle, sc, w, h, cycles, depth, kernel=kernel, keep=ALL, **kw)
+
+
+def _oracle(oracle, sc, w, h, cycles, depth, **kw):
+    op = oracle.Pipeline(sc, w, h, depth=depth, seed_raygen=1, seed_trace=2, **kw)
+    op.render(cycles * depth)
+    o = dict(output=op.output(), result=op.result(), emitted=op.emitted(), rays=op.rays().view(np.float32).reshape(-1, 8))
+    op.close()
+    return o
+
+
+def _outliers(device, sc):
+    """(found, listed) of a fused build of the scene."""
+    from gpuraytracer_amd.runtime import Accel
+    n = len(sc["indices"]) // 3
+    idx, vtx = device.upload(sc["indices"]), device.upload(sc["vertices"])
+    bvh = device.alloc(32 * device.lib.rt_bvh_node_count(n))
+    acc = Accel(device, n)
+    acc.pack(n, idx, vtx)
+    acc.build(sc["scene_min"], sc["scene_max"], bvh)
+    found, listed = C.c_uint32(0), C.c_uint32(0)
+    assert device.lib.rt_accel_outliers(acc.handle, C.byref(found), C.byref(listed)) == 0
+    acc.destroy()
+    for b in (idx, vtx, bvh):
+        b.free()
+    return found.value, listed.value
+
+
+@pytest.mark.parametrize("big,small", [(12, 3000), (64, 3000), (65, 3000), (200, 2000), (20, 0), (7, 1), (3, 0), (40, 5)])
+def test_outliers_are_tested_from_the_list_and_change_nothing(device, oracle, big, small):
+    """Scenes with `big` triangles that span the scene among `small` little ones: up to 64 of the big ones leave the
+    library's own hierarchy for the list (the rest stay in it), whole scenes may consist of them, and every buffer is
+    the oracle's."""
+    from tests.test_gpu_round2 import _same
+    rng = np.random.RandomState(100 + big + small)
+    parts = [_sheets(big, rng)]
+    if small:
+        parts.append(_soup(small, rng))
+    pos = np.concatenate(parts)
+    pos = pos[rng.permutation(len(pos))]
+    sc = _scene_of(pos, "sheets-%d-%d" % (big, small))
+    found, listed = _outliers(device, sc)
+    assert listed == min(found, 64) and found >= min(big, 3), (found, listed)
+    if small >= 1000:
+        assert found <= big + 4            # the little triangles are none
+    w, h, cycles, depth = 96, 54, 2, 3
+    want = _oracle(oracle, sc, w, h, cycles, depth)
+    for kernel in (KERNEL_SPATIAL, KERNEL_QUAD):
+        _same(_render(device, oracle, sc, w, h, cycles, depth, kernel), want, "%d sheets + %d, kernel %d" % (big, small, kernel))
+    if big + small >= 8:                   # (fewer triangles than materials: there may be no light among them)
+        assert want["output"][..., :3].max() > 0.0
+
+
+def test_synthetic_scene_lists_its_twelve_wall_triangles(device):
+    from gpuraytracer_amd import scenes
+    assert _outliers(device, scenes.synthetic_scene(20000)) == (12, 12)
+    assert _outliers(device, scenes.synthetic_scene(15)) == (12, 12)
+
+
+def test_flat_scene_has_no_outliers_by_area_zero(device, oracle):
+    """All centroids in one plane and on one line: the box of the centroids has no surface, so nothing is an outlier."""
+    from tests.test_gpu_round2 import _same
+    rng = np.random.RandomState(5)
+    n = 500
+    c = np.zeros((n, 1, 3), dtype=np.float32)
+    c[:, 0, 0] = rng.uniform(-5, 5, n)
+    tri = np.array([[0, -0.2, -0.2], [0, 0.2, -0.2], [0, 0.0, 0.2]], dtype=np.float32)      # same shape: centroids on the x axis
+    sc = _scene_of(c + tri[None], "line", camera=dict(position=(0.0, 0.0, -12.0), focus=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=1.2,
+                                                   near_z=0.01, far_z=10000.0))
+    assert _outliers(device, sc) == (0, 0)
+    w, h, cycles, depth = 64, 36, 1, 3
+    _same(_render(device, oracle, sc, w, h, cycles, depth, KERNEL_SPATIAL), _oracle(oracle, sc, w, h, cycles, depth), "line of triangles")
+
+
+@pytest.mark.parametrize("kernel", [KERNEL_SPATIAL, KERNEL_SIMPLE])
+def test_pixel_data_of_other_rows_still_scatters_the_ray(device, oracle, kernel):
+    """A ray whose pixel data points outside the rows a device holds: the reference's out-of-range buffer access reads zeros
+    and drops the light writes, but the ray is scattered like any other (shader/CS_TraceRays.hlsl:245-291)."""
+    from gpuraytracer_amd import capi, scenes
+    from gpuraytracer_amd.pipeline import Pipeline
+    sc = scenes.synthetic_scene(3000)
+    w, h = 64, 40
+    cam = sc["camera"]
+    iv, ip = oracle.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], w / h, cam["near_z"], cam["far_z"])
+    capi.check(device.lib.rt_device_set_trace_kernel(device.handle, kernel), "rt_device_set_trace_kernel")
+    try:
+        def run(tamper):
+            seeds = iter([(11, 12, 13), (21, 22, 23)])
+            gp = Pipeline(device, sc, w, h, iv, ip, depth=3, raygen_seeds=lambda: next(seeds), trace_seeds=lambda: next(seeds),
+                          first_row=0, num_rows=h // 2)
+            gp.build()
+            gp.camera_rays()
+            n = gp.local_rays
+            px = gp.ray_pixels.download(np.uint32, n)
+            if tamper is not None:
+                px[tamper] = (px[tamper] & np.uint32(0xffff0000)) | np.uint32(h - 1)      # a row of the other half
+                gp.ray_pixels.upload(px)
+            gp.trace()
+            out = dict(rays=gp.rays.download(np.float32, 8 * n).reshape(-1, 8), old=gp.old_rays.download(np.float32, 8 * n).reshape(-1, 8),
+                       s=gp.scattered.download(np.float32, 4 * n).reshape(-1, 4), e=gp.emitted.download(np.float32, 4 * n).reshape(-1, 4))
+            gp.close()
+            return out
+        plain = run(None)
+        victims = np.arange(5, w * (h // 2), 97)
+        odd = run(victims)
+    finally:
+        device.lib.rt_device_set_trace_kernel(device.handle, KERNEL_SPATIAL)
+    assert (plain["rays"][victims, 3:6] != 0).any()                  # they were hit and scattered in the plain run
+    for k in ("rays", "old"):
+        assert odd[k].tobytes() == plain[k].tobytes(), k + ": the ray itself does not depend on where its light goes"
+    keep = np.ones(len(plain["s"]), dtype=bool)
+    keep[victims] = False
+    assert odd["s"][keep].tobytes() == plain["s"][keep].tobytes() and odd["e"][keep].tobytes() == plain["e"][keep].tobytes()
+    assert not odd["s"][victims].any() and not odd["e"][victims].any()      # dropped writes: still the zeros of a new buffer
