@@ -95,6 +95,7 @@ _SZ = C.c_size_t
 SIGNATURES = {
     "rt_device_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "rt_device_destroy": (C.c_int, [_P]),
+    "rt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "rt_device_sync": (C.c_int, [_P]),
     "rt_device_stream": (_P, [_P]),
     "rt_device_set_stream": (C.c_int, [_P, _P]),

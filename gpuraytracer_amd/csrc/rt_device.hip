@@ -140,6 +140,13 @@ int rt_device_set_stream(rt_device* dev, void* hip_stream) {
 
 int rt_device_index(rt_device* dev) { return dev ? dev->gpu : -1; }
 
+int rt_device_count(int* count) {
+    if (!count) return RT_ERR_INVALID_ARGUMENT;
+    *count = 0;
+    RT_HIP(hipGetDeviceCount(count));
+    return RT_OK;
+}
+
 const char* rt_error_string(int code) {
     switch (code) {
         case RT_OK: return "ok";

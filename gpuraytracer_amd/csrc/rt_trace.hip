@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                                                        uint2* __restrict__ flagged,
                                                        uint32_t* __restrict__ flag_count, unsigned long long* __restrict__ walk_stats,
                                                        const uint32_t* __restrict__ live, const float4* __restrict__ outlier_leaves,
-                                                       const uint32_t* __restrict__ outlier_count) {
+                                                       const uint32_t* __restrict__ outlier_count, const uint8_t* __restrict__ skip) {
     extern __shared__ uint32_t s_dyn[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     uint32_t num_rays = p.num_rays, queue_chunk = p.queue_chunk;      // (the kernel argument itself stays untouched: in registers)
@@ -1114,7 +1114,9 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                 if (mine < q_end) {
                     const uint32_t slot = mine - q_begin;
                     const uint32_t pos = (((slot >> p.deal_shift) * 8u + q) << p.deal_shift) | (slot & ((1u << p.deal_shift) - 1u));
-                    if (pos < num_rays) {
+                    // (skip: rays as they come in drop-missed-rays mode - a ray that has missed is passed over here; where the
+                    // rays are ordered, such rays lie behind the first *live entries and are never handed out)
+                    if (pos < num_rays && !(skip && skip[order ? order[pos].y : pos])) {
                         valid = true;
                         c_rid = order ? order[pos].y : pos;
                         const float4 r0 = rays[2 * (size_t)c_rid], r1 = rays[2 * (size_t)c_rid + 1];
@@ -1517,7 +1519,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     // leaves and does better with fuller rounds)
     const uint32_t leaf_threshold = tune.leaf_threshold ? tune.leaf_threshold : (spatial_kernel ? 32u : 16u);
     const uint32_t blocks_per_cu = tune.blocks_per_cu;
-    const uint32_t sort_rays = tune.sort_rays == 2u ? ((spatial_kernel && !dev->drop_missed && !stats) ? 0u : 1u) : tune.sort_rays;
+    const uint32_t sort_rays = tune.sort_rays == 2u ? ((spatial_kernel && !stats) ? 0u : 1u) : tune.sort_rays;
     dev->listed_valid = false;
 
     TraceParams p;
@@ -1599,8 +1601,9 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     }
 
     RT_HIP(hipMemsetAsync(dev->queue_counter, 0, 1024, s));
-    // the traversal only leaves dead rays out where it walks the rays in a sorted order; otherwise it walks them all
-    // again (they miss again) and only the marks are kept
+    // Where the rays are walked in a sorted order, the dead ones lie behind the first *live entries and are never handed
+    // out; the default kernel, taking rays as they come, passes over marked rays when it fills its stock; the other kernels
+    // without an order walk them all again (they miss again) and only the marks are kept
     uint32_t* live = (missed && sort_rays) ? dev->queue_counter + 129 : nullptr;
     // persistent grid: enough workgroups to fill every CU, never more than there are rays to hand out
     uint32_t groups = (uint32_t)dev->compute_units * blocks_per_cu;
@@ -1712,7 +1715,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
                        (const float4*)accel->sp_nodes, (const float4*)accel->sp_pairs, (const float4*)accel->sp_quads,          \
                        (const float4*)accel->sp_tris, dev->hit_records, dev->hit_ci, dev->queue_counter, order, st,            \
                        dev->listed_rays, listed, dev->walk_stats, (const uint32_t*)live, (const float4*)accel->outlier_leaves,   \
-                       (const uint32_t*)(accel->cells + RT_CELLS_OUTLIERS))
+                       (const uint32_t*)(accel->cells + RT_CELLS_OUTLIERS), (const uint8_t*)((missed && !live) ? missed : nullptr))
         if (dev->walk_stats) RT_LAUNCH_SPATIAL(true);
         else RT_LAUNCH_SPATIAL(false);
 #undef RT_LAUNCH_SPATIAL

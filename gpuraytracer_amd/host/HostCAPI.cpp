@@ -5,6 +5,7 @@
 #include <iostream>
 #include <vector>
 
+#include "RankGate.h"
 #include "RaytracerPipeline.h"
 #include "Scenes.h"
 
@@ -172,4 +173,11 @@ int rth_write_pfm(const char* path, const float* pixels, uint32_t w, uint32_t h)
 int rth_write_png(const char* path, const float* pixels, uint32_t w, uint32_t h) { return WriteImagePNG(path, pixels, w, h) ? 1 : 0; }
 uint32_t rth_encode_srgb8(float linear) { return EncodeSRGB8(linear); }
 
-}  // extern "C"
+// ---- the gate the rank threads of rt_headless --ranks meet at before a collective (RankGate.h) ----
+RankGate* rth_gate_create(int world) { return new RankGate(world); }
+int rth_gate_arrive(RankGate* g, int well) { return g->Arrive(well != 0) ? 1 : 0; }
+void rth_gate_leave(RankGate* g) { g->Leave(); }
+int rth_gate_failed(RankGate* g) { return g->Failed() ? 1 : 0; }
+void rth_gate_destroy(RankGate* g) { delete g; }
+
+}

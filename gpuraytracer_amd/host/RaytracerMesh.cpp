@@ -1134,7 +1134,7 @@ namespace RT::GraphicsAPI
 		Release();
 	}
 
-	bool RaytracerMesh::Initialize(rt_device* rtDevice, MeshInfo rtMesh)
+	bool RaytracerMesh::Initialize(rt_device* rtDevice, MeshInfo rtMesh, bool bTakeOwnership)
 	{
 		m_rtDevice = rtDevice;
 		if (!m_rtDevice || !rtMesh.Indices || !rtMesh.Vertices) return false;
@@ -1146,9 +1146,12 @@ namespace RT::GraphicsAPI
 		if (rt_buffer_upload(m_rtVertexBuffer, rtMesh.Vertices, iVertexBytes, 0) != RT_OK) return false;
 
 		//the mesh data now lives on the gpu
-		delete[] rtMesh.Indices;
-		delete[] rtMesh.Vertices;
-		delete[] rtMesh.Materials;
+		if (bTakeOwnership)
+		{
+			delete[] rtMesh.Indices;
+			delete[] rtMesh.Vertices;
+			delete[] rtMesh.Materials;
+		}
 		m_rtMesh.Indices = nullptr;
 		m_rtMesh.Vertices = nullptr;
 		m_rtMesh.Materials = nullptr;

@@ -108,7 +108,8 @@ namespace RT::GraphicsAPI
 
 		//uploads indices and vertices; takes ownership of and deletes rtMesh.Indices / Vertices / Materials
 		//afterwards, as the reference does
-		bool Initialize(rt_device* rtDevice, MeshInfo rtMesh);
+		//(bTakeOwnership = false: the arrays stay the caller's, e.g. for the next device's pipeline)
+		bool Initialize(rt_device* rtDevice, MeshInfo rtMesh, bool bTakeOwnership = true);
 		//the two resources a shader binds at t0 / t1
 		void Bind(const rt_buffer** rtIndexBuffer, const rt_buffer** rtVertexBuffer) const;
 		void Release();

@@ -415,7 +415,7 @@ namespace RT::GraphicsAPI
 
 		//the mesh (deletes the host arrays of rtMeshData once they are uploaded)
 		m_rtMesh = new RaytracerMesh();
-		if (!(m_rtMesh->Initialize(m_rtDevice, rtMeshData))) return false;
+		if (!(m_rtMesh->Initialize(m_rtDevice, rtMeshData, !rtSettings.SharedMesh))) return false;
 
 		m_rtInfoData.screen_dimensions[0] = (int32_t)rtSettings.WindowWidth;
 		m_rtInfoData.screen_dimensions[1] = (int32_t)rtSettings.WindowHeight;
@@ -677,6 +677,9 @@ namespace RT::GraphicsAPI
 	bool RaytracerPipeline::SaveState(const std::string& sFileName)
 	{
 		if (m_iIteration != 0 || m_rtSettings.DeviceCount != 1) return false;		//only between two sample cycles, of a whole image
+		//a refitted hierarchy keeps the order of the run's first build, which the file does not hold: a resumed run would refit
+		//over another order and continue the uninterrupted one only up to ties between equal hit distances
+		if (m_rtSettings.RefitBVH) return false;
 		const size_t iPixels = (size_t)m_rtSettings.WindowWidth * m_rtSettings.WindowHeight;
 		std::vector<float> stdPixels(iPixels * 4);
 		if (!ReadResult(stdPixels.data())) return false;
@@ -691,7 +694,7 @@ namespace RT::GraphicsAPI
 
 	bool RaytracerPipeline::LoadState(const std::string& sFileName)
 	{
-		if (m_iIteration != 0 || m_rtSettings.DeviceCount != 1) return false;
+		if (m_iIteration != 0 || m_rtSettings.DeviceCount != 1 || m_rtSettings.RefitBVH) return false;
 		std::ifstream stdFile(sFileName, std::ios::binary);
 		if (!stdFile) return false;
 		std::string sMagic;

@@ -226,7 +226,8 @@ namespace RT::GraphicsAPI
 		bool GatherOutput(rt_comm* rtComm, rt_buffer* rtImage);
 		//checkpoint of the accumulation (the reference has none: its state lives in ResultBuffer, NumSamples and its two
 		//host generators): the running-mean image, the sample counter, both std::mt19937 states and the frame of a moving
-		//scene, written / restored between two sample cycles, so that k cycles + resume + k cycles = 2k cycles
+		//scene, written / restored between two sample cycles, so that k cycles + resume + k cycles = 2k cycles.
+		//Refused with Settings::RefitBVH: refits keep the order of the run's first build, which the file does not hold
 		bool SaveState(const std::string& sFileName);
 		bool LoadState(const std::string& sFileName);
 		uint32_t GetNumSamples() const { return m_rtImageGeneration ? m_rtImageGeneration->GetNumSamples() : 0; };

@@ -69,6 +69,8 @@ namespace RT
 		uint32_t LoaderThreads = 0;         //threads LoadMeshFromFile parses the OBJ file with (1 = line by line; 0 = by file size and cores)
 		uint32_t DeviceRank = 0;            //multi-GPU: this pipeline renders the image rows DeviceRank, DeviceRank + DeviceCount, ...
 		uint32_t DeviceCount = 1;           //(one pipeline per GPU, same scene and seeds on each; RaytracerPipeline::GatherOutput assembles the image)
+		bool SharedMesh = false;            //the MeshInfo handed to Initialize stays the caller's (its arrays are uploaded, not freed): several
+		                                    //pipelines - one per GPU - are made from one loaded scene
 		uint32_t SeedRayGen = 0;            //std::mt19937 seeds of the two host generators; 0 = std::random_device
 		uint32_t SeedTrace = 0;
 	};

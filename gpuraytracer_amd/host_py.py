@@ -41,6 +41,8 @@ def load():
         "rth_load_mesh_dedup": (_P, [C.c_char_p]),
         "rth_load_mesh_threads": (_P, [C.c_char_p, C.c_int, C.c_uint32]),
         "rth_synthetic_scene": (_P, [C.c_uint32, C.c_uint32]),
+        "rth_gate_create": (_P, [C.c_int]), "rth_gate_arrive": (C.c_int, [_P, C.c_int]), "rth_gate_leave": (None, [_P]),
+        "rth_gate_failed": (C.c_int, [_P]), "rth_gate_destroy": (None, [_P]),
         "rth_mesh_index_count": (C.c_uint64, [_P]), "rth_mesh_vertex_count": (C.c_uint64, [_P]),
         "rth_mesh_material_count": (C.c_uint64, [_P]), "rth_mesh_texture_count": (C.c_uint64, [_P]),
         "rth_mesh_texture_name": (C.c_char_p, [_P, C.c_uint64]),

@@ -82,6 +82,7 @@ int rt_device_sync(rt_device* dev);                      /* GPUScheduler::Flush 
 void* rt_device_stream(rt_device* dev);                  /* the hipStream_t launches go to */
 int rt_device_set_stream(rt_device* dev, void* hip_stream); /* adopt a caller-owned stream (not destroyed here) */
 int rt_device_index(rt_device* dev);
+int rt_device_count(int* count);                         /* GPUs this process sees (the reference takes the first adapter, src/GPUDevice.cpp:40-91) */
 const char* rt_error_string(int code);
 
 /* Which traversal kernel rt_trace_rays / rt_trace_rays_accel launch (no counterpart in the reference).
@@ -126,8 +127,7 @@ typedef struct {
     uint32_t refill_threshold;  /* GPURT_REFILL_THRESHOLD: free lanes that start a refill; 0 = 8 (SPATIAL) / 16 */
     uint32_t blocks_per_cu;     /* GPURT_BLOCKS_PER_CU: persistent workgroups per compute unit; default 4 */
     uint32_t sort_rays;         /* GPURT_SORT_RAYS: 1 = order the rays of a launch by estimated walk length, 0 = as they come,
-                                   2 (default) = order them for the walks in the reference's order and where missed rays are
-                                   dropped, not for the default kernel (its walks are short and alike: measured, the order
+                                   2 (default) = order them for the walks in the reference's order, not for the default kernel (its walks are short and alike: measured, the order
                                    costs what it gains) */
     uint32_t deal_shift;        /* GPURT_DEAL_SHIFT: log2 of the block of ray-order positions dealt to one queue; 6 .. 20, default 6 */
     uint32_t cost_bits;         /* GPURT_COST_BITS: bits of the walk-length class in the ray key; 6 .. 12, default 6 */

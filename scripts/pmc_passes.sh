@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 run_pass() {
   name=$1; shift
-  timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pass_$name" -o p -- python bench.py --no-cpu-baseline --no-reference-walk --steps 1 --warmup 0 $BENCH_ARGS > "$OUT/pass_$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$OUT/pass_$name.log"; return 1; }
+  timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pass_$name" -o p -- python bench.py --no-others --no-cpu-baseline --no-reference-walk --steps 1 --warmup 0 $BENCH_ARGS > "$OUT/pass_$name.log" 2>&1 || { echo "pass $name failed"; tail -3 "$OUT/pass_$name.log"; return 1; }
   echo "pass $name ok"
 }
 BENCH_ARGS="$*"

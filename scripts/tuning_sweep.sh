@@ -4,7 +4,7 @@ out=gpurun_out/tuning_sweep.txt
 : > $out
 run() {
   echo "== $*" >> $out
-  env "$@" timeout -k 10 150 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-counters --no-reference-walk \
+  env "$@" timeout -k 10 150 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-counters --no-reference-walk --no-others \
     | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print(d['value'], r['avg_launch_ms'], d['trace_ms_by_bounce'])" >> $out || exit 1
 }
 for t in 16 24 32 40 48; do run GPURT_LEAF_THRESHOLD=$t; done

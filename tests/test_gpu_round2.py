@@ -612,7 +612,8 @@ def _open_scene(n, seed=5):
 
 
 @pytest.mark.parametrize("kernel,use_bvh,sort_rays", [(KERNEL_SPATIAL, True, 1), (KERNEL_QUAD, True, 1), (KERNEL_WAVE, True, 1),
-                                                        (KERNEL_SIMPLE, True, 1), (KERNEL_SPATIAL, False, 1), (KERNEL_SPATIAL, True, 0)])
+                                                        (KERNEL_SIMPLE, True, 1), (KERNEL_SPATIAL, False, 1), (KERNEL_SPATIAL, True, 0),
+                                                        (KERNEL_SPATIAL, True, 2), (KERNEL_QUAD, True, 0)])
 def test_dropping_missed_rays_changes_no_buffer(device, oracle, kernel, use_bvh, sort_rays):
     """rt_device_set_drop_missed_rays: rays that missed are left out of the later bounces of their sample cycle instead
     of being traced again (the reference's behaviour, shader/CS_TraceRays.hlsl:248,290-291). A ray that missed would

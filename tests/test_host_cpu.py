@@ -499,3 +499,80 @@ def test_parser_threads_report_the_first_error_as_the_serial_parser_does(tmp_pat
             messages.append(capfd.readouterr().out.strip())
         assert messages[0].startswith("Error loading scene:") and "line" in messages[0], (name, messages[0])
         assert all(m == messages[0] for m in messages), (name, messages)
+
+
+# ------------------------------------------------------------------ the gate of a device group (rt_headless --ranks) ----
+
+def _gate_run(world, plan, timeout=20.0):
+    """Runs one thread per rank; plan[r] is a list of steps: ("arrive", well) -> records what the gate said, ("leave",).
+    Returns the records per rank; fails if a thread does not come back (a rank left waiting for ever)."""
+    import threading
+    from gpuraytracer_amd import host_py
+    lib = host_py.load()
+    gate = lib.rth_gate_create(world)
+    said = [[] for _ in range(world)]
+
+    def rank(r):
+        for step in plan[r]:
+            if step[0] == "arrive":
+                said[r].append(lib.rth_gate_arrive(gate, 1 if step[1] else 0))
+            elif step[0] == "leave":
+                lib.rth_gate_leave(gate)
+                return
+            elif step[0] == "sleep":
+                import time
+                time.sleep(step[1])
+
+    threads = [threading.Thread(target=rank, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout)
+        assert not t.is_alive(), "a rank is still waiting at the gate"
+    failed = lib.rth_gate_failed(gate)
+    lib.rth_gate_destroy(gate)
+    return said, failed
+
+
+def test_rank_gate_opens_for_a_healthy_group():
+    said, failed = _gate_run(4, [[("arrive", True), ("arrive", True), ("arrive", True)]] * 4)
+    assert said == [[1, 1, 1]] * 4 and failed == 0
+
+
+def test_rank_gate_tells_everyone_about_a_rank_that_arrives_unwell():
+    plan = [[("arrive", True), ("arrive", True)] for _ in range(3)]
+    plan[1] = [("arrive", True), ("arrive", False)]
+    said, failed = _gate_run(3, plan)
+    assert said == [[1, 0]] * 3 and failed == 1
+
+
+def test_rank_gate_does_not_wait_for_a_rank_that_has_left():
+    """A rank that fails before the first collective (its device could not be created, say) leaves; the others are told at
+    the gate instead of waiting inside the collective for ever, and every later gate opens at once, closed for business."""
+    plan = [[("arrive", True), ("arrive", True)] for _ in range(4)]
+    plan[2] = [("leave",)]
+    said, failed = _gate_run(4, plan)
+    assert failed == 1
+    assert said[2] == [] and all(s == [0, 0] for r, s in enumerate(said) if r != 2)
+    # ... also when the others are already waiting when it leaves
+    plan = [[("arrive", True)] for _ in range(3)]
+    plan[0] = [("sleep", 0.3), ("leave",)]
+    said, failed = _gate_run(3, plan)
+    assert said[1] == [0] and said[2] == [0] and failed == 1
+    # ... and when it leaves between two gates
+    plan = [[("arrive", True), ("arrive", True)] for _ in range(3)]
+    plan[1] = [("arrive", True), ("leave",)]
+    said, failed = _gate_run(3, plan)
+    assert said[0] == [1, 0] and said[2] == [1, 0] and said[1] == [1]
+
+
+def test_headless_cli_refuses_more_ranks_than_devices():
+    """rt_headless --ranks N beyond the GPUs of the machine ends at once with a non-zero code (on a machine without a GPU:
+    because the devices cannot even be counted), instead of starting threads that wait for each other."""
+    import subprocess
+    exe = os.path.join(ROOT, "gpuraytracer_amd", "bin", "rt_headless")
+    if not os.path.exists(exe):
+        pytest.skip("rt_headless is not built")
+    r = subprocess.run([exe, "--synthetic", "100", "--width", "32", "--height", "18", "--ranks", "99"], capture_output=True, text=True, timeout=60)
+    assert r.returncode in (1, 2), r.stdout + r.stderr
+    assert "ranks" in r.stdout or "devices" in r.stdout
