@@ -70,6 +70,25 @@ MeshInfo* rth_synthetic_scene(uint32_t n, uint32_t seed)
 	if (!m.Vertices) return nullptr;
 	return new MeshInfo(m);
 }
+//a MeshInfo from arrays (a soup: indices 0 .. vertex_count - 1; no textures beyond the built-in slot 0), e.g. a loader fixture;
+//the centroid bounds are computed as the loader computes them
+MeshInfo* rth_mesh_from_arrays(const void* vertices, uint64_t vertex_count, const void* materials, uint64_t material_count)
+{
+	if (!vertices || !materials || vertex_count < 9 || vertex_count % 3 || !material_count) return nullptr;
+	MeshInfo m{};
+	m.IndexCount = m.VertexCount = vertex_count;
+	m.Indices = new Index[vertex_count];
+	for (uint64_t i = 0; i < vertex_count; i++) m.Indices[i] = (Index)i;
+	m.Vertices = new Vertex[vertex_count];
+	std::memcpy(m.Vertices, vertices, vertex_count * sizeof(Vertex));
+	m.MaterialCount = material_count;
+	m.Materials = new PBRMaterial[material_count];
+	std::memcpy(m.Materials, materials, material_count * sizeof(PBRMaterial));
+	m.TextureNameCount = 1;
+	m.TextureNames = new std::string[1];
+	m.SceneAABB = CalculateCentroidBounds(m);
+	return new MeshInfo(m);
+}
 uint64_t rth_mesh_index_count(const MeshInfo* m) { return m->IndexCount; }
 uint64_t rth_mesh_vertex_count(const MeshInfo* m) { return m->VertexCount; }
 uint64_t rth_mesh_material_count(const MeshInfo* m) { return m->MaterialCount; }

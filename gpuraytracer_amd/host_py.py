@@ -41,6 +41,7 @@ def load():
         "rth_load_mesh_dedup": (_P, [C.c_char_p]),
         "rth_load_mesh_threads": (_P, [C.c_char_p, C.c_int, C.c_uint32]),
         "rth_synthetic_scene": (_P, [C.c_uint32, C.c_uint32]),
+        "rth_mesh_from_arrays": (_P, [_P, C.c_uint64, _P, C.c_uint64]),
         "rth_gate_create": (_P, [C.c_int]), "rth_gate_arrive": (C.c_int, [_P, C.c_int]), "rth_gate_leave": (None, [_P]),
         "rth_gate_failed": (C.c_int, [_P]), "rth_gate_destroy": (None, [_P]),
         "rth_mesh_index_count": (C.c_uint64, [_P]), "rth_mesh_vertex_count": (C.c_uint64, [_P]),
@@ -168,6 +169,10 @@ class HostPipeline:
         self.local_rows = max(0, (height - device_rank + device_count - 1) // device_count)
         if isinstance(mesh_source, int):
             mesh = self.lib.rth_synthetic_scene(mesh_source, 12345)
+        elif isinstance(mesh_source, dict):          # a scene held in arrays (a triangle soup without textures)
+            v = np.ascontiguousarray(mesh_source["vertices"])
+            m = np.ascontiguousarray(mesh_source["materials"])
+            mesh = self.lib.rth_mesh_from_arrays(v.ctypes.data_as(C.c_void_p), len(v), m.ctypes.data_as(C.c_void_p), len(m))
         else:
             mesh = self.lib.rth_load_mesh(str(mesh_source).encode())
         if not mesh:

@@ -31,6 +31,13 @@ def main():
     note = sys.argv[4] if len(sys.argv) > 4 else ""
     prof = os.path.join(ROOT, "profiles")
     pre = os.path.join(prof, "%s_%s_" % (rnd, wl))
+    sys.path.insert(0, ROOT)
+    from bench import source_sha
+    import subprocess
+    head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "gpuraytracer_amd/csrc", "include"], cwd=ROOT, capture_output=True,
+                                text=True).stdout.strip())
+    stamp = "state: git %s%s, kernel sources %s" % (head[:12], " + uncommitted changes to the kernel sources" if dirty else "", source_sha())
     stats = src + "prof/p_kernel_stats.csv"
     if os.path.exists(stats):
         rows = list(csv.DictReader(open(stats)))
@@ -39,7 +46,7 @@ def main():
                "k_traverse_quad alone (the walk in the reference's order), 1 frame by the counting variant k_traverse_spatial<true> and "
                "1 frame counting the reference's tests (k_traverse<true, false>); k_traverse_quad is also launched after every "
                "k_traverse_spatial for the listed rays and returns at once when there are none, so its average mixes both",
-               note, "",
+               note, stamp, "",
                "%-44s %6s %14s %14s %8s" % ("kernel", "calls", "total ms", "average us", "percent")]
         for r in rows:
             out.append("%-44s %6d %14.3f %14.3f %8.3f" % (short(r["Name"])[:44], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6,
@@ -52,6 +59,15 @@ def main():
                  ("pmc.json", "pmc.json")):
         if os.path.exists(src + a) and os.path.getsize(src + a):
             shutil.copy(src + a, pre + b)
+    if os.path.exists(pre + "pmc.json"):
+        table = json.load(open(pre + "pmc.json"))
+        if table.get("source_sha") != source_sha():
+            print("WARNING: the counter passes were taken on other kernel sources (%s) than this tree's (%s)" % (table.get("source_sha"), source_sha()))
+        table["head"] = head + ("+" if dirty else "")
+        json.dump(table, open(pre + "pmc.json", "w"), indent=1, sort_keys=True)
+    if os.path.exists(pre + "pmc_summary.txt"):
+        text = open(pre + "pmc_summary.txt").read()
+        open(pre + "pmc_summary.txt", "w").write(stamp + "\n" + text)
     if os.path.exists(src + "bench.json"):
         d = json.load(open(src + "bench.json"))
         print("bench:", d["value"], d["unit"], "ms/step", d["ms_per_step"], "traverse launch ms", d["roofline"]["avg_launch_ms"], "build ms",

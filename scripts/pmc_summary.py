@@ -33,7 +33,10 @@ def main(root, json_path=None):
             print("    %-36s total %18.0f  per-dispatch %16.1f  (%d dispatches)" % (c, table[k][c], table[k][c] / n, n))
     if json_path:
         with open(json_path, "w") as f:
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from bench import source_sha                  # the kernels these counters were taken on
             json.dump({"source": "rocprofv3 --pmc, one run per counter group (scripts/pmc_passes.sh); values are per dispatch",
+                       "source_sha": source_sha(),
                        "kernels": {k: {c: table[k][c] / calls[k][c] for c in sorted(table[k])} for k in sorted(table)},
                        "dispatches": {k: max(calls[k].values()) for k in sorted(table)}}, f, indent=1, sort_keys=True)
 

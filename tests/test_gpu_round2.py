@@ -169,18 +169,19 @@ def test_testscene2_has_the_structure_of_the_reference_screenshot(device):
 # ------------------------------------------------------------------ C4: rows dealt to 8 pseudo-ranks ----
 
 def test_c4_rows_dealt_to_eight_ranks_assemble_to_the_unsharded_image(device, oracle):
-    """BASELINE config 4 on one GPU: the 10M-triangle scene at 3840x2160, 2 rays per pixel, traced once whole and once
+    """BASELINE config 4 on one GPU: the 10M-triangle scene at 3840x2160, 4 rays per pixel, 3 accumulated sample cycles
+    of 3 bounces (towards the configuration's 64 samples per pixel: rays per pixel x cycles), traced once whole and once
     as eight pipelines that each hold the rows r, r + 8, ... (replicated scene, own rebuild): the rows, put back in
     place, are the unsharded image bit for bit."""
     from gpuraytracer_amd import host_py
     from gpuraytracer_amd.distributed import rows_for_rank
     sc = host_py.synthetic_scene(10_000_000)
-    w, h, depth, rpp, world = 3840, 2160, 2, 2, 8
-    full = _gpu_render(device, oracle, sc, w, h, 1, depth, rpp=rpp, keep=("output", "result"))
+    w, h, depth, rpp, world, cycles = 3840, 2160, 3, 4, 8, 3
+    full = _gpu_render(device, oracle, sc, w, h, cycles, depth, rpp=rpp, keep=("output", "result"))
     parts = {k: np.zeros_like(v) for k, v in full.items()}
     for r in range(world):
         first, rows, stride = rows_for_rank(h, world, r)
-        got = _gpu_render(device, oracle, sc, w, h, 1, depth, rpp=rpp, keep=("output", "result"), first_row=first, num_rows=rows,
+        got = _gpu_render(device, oracle, sc, w, h, cycles, depth, rpp=rpp, keep=("output", "result"), first_row=first, num_rows=rows,
                           row_stride=stride)
         for k in parts:
             parts[k][r::world] = got[k]
@@ -281,6 +282,22 @@ def test_c5_fifty_million_moving_triangles(device, oracle):
     q = _gpu_render(device, oracle, sc, w, h, 2, depth, kernel=KERNEL_QUAD, keep=ALL, dynamic=True)
     _same(a, q, "C5 480x270: SPATIAL vs QUAD")
     assert a["output"][..., :3].max() > 0.0
+    del a, q
+    # The configuration's own frame, 7680x4320 and 4 bounces, by the default kernel - and every 64th row of it alone
+    # (rt_image_rows) by the walk in the reference's order, which would take minutes for the whole frame. Seeds and pixel
+    # coordinates are those of the whole image, so the half million rays of those rows must equal the same rows of the
+    # full frame bit for bit.
+    w, h, depth, first, stride = 7680, 4320, 4, 17, 64
+    keep = ("output", "emitted", "rays")
+    rows = len(range(first, h, stride))
+    part = _gpu_render(device, oracle, sc, w, h, 1, depth, kernel=KERNEL_QUAD, keep=keep, dynamic=True, first_row=first, num_rows=rows,
+                       row_stride=stride)
+    full = _gpu_render(device, oracle, sc, w, h, 1, depth, kernel=KERNEL_SPATIAL, keep=keep, dynamic=True)
+    assert full["output"].shape[0] == h and part["output"].shape[0] == rows
+    assert full["output"][first::stride].tobytes() == part["output"].tobytes(), "C5 at 8K: tone-mapped rows differ"
+    assert full["rays"].reshape(h, w, 8)[first::stride].tobytes() == part["rays"].tobytes(), "C5 at 8K: rays differ"
+    assert full["emitted"].reshape(h, w, 4)[first::stride].tobytes() == part["emitted"].tobytes(), "C5 at 8K: emitted light differs"
+    assert part["output"][..., :3].max() > 0.0
 
 
 # ------------------------------------------------------------------ what the default kernel's two margins are for ----

@@ -163,3 +163,36 @@ def test_pixel_data_of_other_rows_still_scatters_the_ray(device, oracle, kernel)
     keep[victims] = False
     assert odd["s"][keep].tobytes() == plain["s"][keep].tobytes() and odd["e"][keep].tobytes() == plain["e"][keep].tobytes()
     assert not odd["s"][victims].any() and not odd["e"][victims].any()      # dropped writes: still the zeros of a new buffer
+
+
+def test_c1_settings_defaults_on_the_substitute_scene(device, oracle):
+    """BASELINE config 1 is the reference's default build: assets/testscene1.obj at the defaults of src/Settings.h:4-20
+    (1280x720, 1 ray per pixel, depth 3, AA spread 1.5, no depth of field, hierarchy on), one sample cycle. That asset is
+    not part of the reference's checkout (a missing large file); assets/testscene2.obj with its own camera
+    (src/Settings.h:22-25) stands in for it. The C++ host with default-constructed Settings and the Python pipeline both
+    give the oracle's image, buffer for buffer."""
+    from gpuraytracer_amd import host_py
+    from tests.test_gpu_round2 import _golden_scene, _same
+    sc = _golden_scene("testscene2")
+    w, h, depth = 1280, 720, 3                     # RT_WINDOW_WIDTH, RT_WINDOW_HEIGHT, RT_MAX_RAY_DEPTH
+    want = _oracle(oracle, sc, w, h, 1, depth)
+    _same(_render(device, oracle, sc, w, h, 1, depth, KERNEL_SPATIAL), want, "C1 defaults, Python pipeline")
+    hp = host_py.HostPipeline(device, sc, w, h, sc["camera"])      # rpp 1, depth 3, aa 1.5, dof 0, hierarchy on: the defaults
+    try:
+        hp.render(depth)
+        assert hp.output().tobytes() == want["output"].tobytes(), "C1 defaults, C++ host: tone-mapped image differs"
+        assert hp.result().tobytes() == want["result"].tobytes(), "C1 defaults, C++ host: accumulated image differs"
+    finally:
+        hp.close()
+    assert want["output"][..., :3].max() > 0.0
+
+
+def test_headless_cli_refuses_more_ranks_than_the_machine_has_gpus(device):
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpuraytracer_amd", "bin", "rt_headless")
+    n = C.c_int(0)
+    assert device.lib.rt_device_count(C.byref(n)) == 0 and n.value >= 1
+    r = subprocess.run([exe, "--synthetic", "100", "--width", "32", "--height", "18", "--ranks", str(n.value + 1)], capture_output=True,
+                       text=True, timeout=60)
+    assert r.returncode == 2 and "this machine shows %d" % n.value in r.stdout, r.stdout + r.stderr

@@ -576,3 +576,21 @@ def test_headless_cli_refuses_more_ranks_than_devices():
     r = subprocess.run([exe, "--synthetic", "100", "--width", "32", "--height", "18", "--ranks", "99"], capture_output=True, text=True, timeout=60)
     assert r.returncode in (1, 2), r.stdout + r.stderr
     assert "ranks" in r.stdout or "devices" in r.stdout
+
+
+# ------------------------------------------------------------------ committed hardware counters and the kernels they belong to ----
+
+def test_committed_counter_files_belong_to_the_kernels_in_the_tree():
+    """bench.py takes roofline.traffic and the vector fractions from profiles/<round>_<workload>_pmc.json. A counter file
+    measured before the last change to the kernel sources says nothing about the kernels that run now: it has to be
+    taken again (scripts/profile_round.sh + scripts/collect_round.py), and until then bench.py withholds the fractions."""
+    import glob
+    import json
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "%s_*_pmc.json" % bench.ROUND)))
+    assert files, "no counter file of this round is committed"
+    sha = bench.source_sha()
+    for f in files:
+        table = json.load(open(f))
+        assert table.get("source_sha") == sha, "%s was measured on kernel sources %s, the tree holds %s" % (os.path.basename(f), table.get("source_sha"), sha)
+        assert table.get("head"), "%s does not name the commit it was collected at" % os.path.basename(f)
