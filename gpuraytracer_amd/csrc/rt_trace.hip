@@ -934,8 +934,13 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
 // behind their own triangles' hits, that is: of all triangles whose leaf box (in the reference's pairing) lets the
 // ray in, the one with the smallest distance, the earlier in the reference's order among equal distances.
 // k_traverse_spatial finds that triangle on a second hierarchy, built by the same kernels from non-overlapping codes
-// of the same centroids (leaves: pairs of neighbours in THAT order, in slots laid out by Morton cell - see
-// k_cell_choose in rt_build.hip), with the step of k_traverse_quad:
+// of the same centroids (leaf slots laid out by Morton cell - see k_cell_choose in rt_build.hip -, the eight triangles
+// under a record paired into leaves by surface area), with the step of k_traverse_quad:
+//  * triangles whose box is a large part of the scene's (outliers: a wall, a floor) are not in that hierarchy, where they
+//    would make every node above them as large as themselves - a dozen such triangles among a million small ones cost
+//    every ray some fifty steps. They are tested from a list, by the whole wave, when it fills its stock of rays; what they
+//    leave (a closest hit, a reach) is where the walk starts from, and a ray that the rest of the scene cannot reach
+//    within that is not walked at all;
 //  * a box is entered while its entry distance does not exceed "reach" (not: is below the closest hit), so that
 //    hits at the same distance are all seen and the order of the reference decides between them;
 //  * for a triangle that is hit, the reference's leaf of it (its place in the reference's order / 2) is fetched and

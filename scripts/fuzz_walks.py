@@ -39,7 +39,7 @@ def random_scene(rng):
     """A triangle soup of a random kind: sizes from specks to slabs across the scene, axis-aligned quads (flat boxes,
     shared edges), slivers (rays nearly in their plane), duplicates (equal distances)."""
     n = int(10 ** rng.uniform(2.0, float(os.environ.get("FUZZ_MAX_EXP", "5.3"))))
-    kinds = ["soup", "big", "quads", "slivers", "duplicates", "clusters", "inplane", "huge", "tiny", "mesh"]
+    kinds = ["soup", "big", "quads", "slivers", "duplicates", "clusters", "inplane", "huge", "tiny", "mesh", "sheets", "room"]
     if os.environ.get("FUZZ_KINDS"):
         kinds = os.environ["FUZZ_KINDS"].split(",")
     kind = rng.choice(kinds)
@@ -59,6 +59,26 @@ def random_scene(rng):
     pos = (c + off).astype(np.float32)
     if kind == "duplicates":
         pos[n // 2:] = pos[:n - n // 2]
+        pos = pos[rng.permutation(n)]
+    if kind == "sheets":                                  # 1 - 150 triangles that span the scene (outliers: tested from a list,
+        k = min(int(rng.randint(1, 151)), n - 1)          # beyond 64 of them the rest stays in the hierarchy) among the soup
+        pos[:k] = (rng.uniform(-12, 12, (k, 1, 3)) + rng.uniform(-25, 25, (k, 3, 3))).astype(np.float32)
+        pos = pos[rng.permutation(n)]
+    if kind == "room" and n >= 40:                        # a closed box around the soup and large axis-aligned panels inside:
+        box = scenes._box_triangles(float(rng.uniform(11, 30)))      # flat outliers whose hits tie with their boxes' entries
+        k = int(rng.randint(0, 13))
+        panels = np.zeros((2 * k, 3, 3), dtype=np.float32)
+        for j in range(k):
+            axis, at = int(rng.randint(0, 3)), float(np.round(rng.uniform(-10, 10) * 4) / 4)
+            u, v2 = [a for a in range(3) if a != axis]
+            lo, hi = np.sort(rng.uniform(-11, 11, (2, 2)), axis=0)
+            q = np.zeros((4, 3), dtype=np.float32)
+            q[:, axis] = at
+            q[:, u] = (lo[0], hi[0], hi[0], lo[0])
+            q[:, v2] = (lo[1], lo[1], hi[1], hi[1])
+            panels[2 * j], panels[2 * j + 1] = q[[0, 1, 2]], q[[0, 2, 3]]
+        extra = np.concatenate([box, panels])
+        pos[:len(extra)] = extra
         pos = pos[rng.permutation(n)]
     v = np.zeros(3 * n, dtype=vertex_dtype)
     v["position"] = pos.reshape(-1, 3)

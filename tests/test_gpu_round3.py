@@ -196,3 +196,49 @@ def test_headless_cli_refuses_more_ranks_than_the_machine_has_gpus(device):
     r = subprocess.run([exe, "--synthetic", "100", "--width", "32", "--height", "18", "--ranks", str(n.value + 1)], capture_output=True,
                        text=True, timeout=60)
     assert r.returncode == 2 and "this machine shows %d" % n.value in r.stdout, r.stdout + r.stderr
+
+
+def test_gather_rows_between_two_gpus(device):
+    """rt_comm_init from two host threads of one process (one per GPU) and rt_gather_rows of an image whose height is odd,
+    so that the ranks hold different numbers of rows: the root's image is the rows in image order. Needs two GPUs (the
+    test boxes have one: skipped there; every wait is bounded so that a failure cannot hang the run)."""
+    import threading
+    from gpuraytracer_amd import capi
+    from gpuraytracer_amd.runtime import Device
+    lib = device.lib
+    n = C.c_int(0)
+    assert lib.rt_device_count(C.byref(n)) == 0
+    if n.value < 2:
+        pytest.skip("one GPU on this machine")
+    world, w, h = 2, 64, 45
+    image = np.random.RandomState(4).uniform(0, 1, (h, w, 4)).astype(np.float32)
+    uid = (C.c_ubyte * capi.RT_COMM_ID_BYTES)()
+    capi.check(lib.rt_comm_unique_id(uid), "rt_comm_unique_id")
+    got, errors = {}, []
+
+    def rank(r):
+        try:
+            dev = Device(r)
+            comm = C.c_void_p()
+            capi.check(lib.rt_comm_init(dev.handle, r, world, uid, C.byref(comm)), "rt_comm_init")
+            rows = capi.ImageRows()
+            capi.check(lib.rt_rows_for_rank(h, world, r, C.byref(rows)), "rt_rows_for_rank")
+            assert (rows.first_row, rows.row_stride, rows.num_rows) == (r, world, len(range(r, h, world)))
+            src = dev.upload(np.ascontiguousarray(image[r::world]))
+            dst = dev.alloc(16 * w * h) if r == 0 else None
+            capi.check(lib.rt_gather_rows(comm, src.handle, w, h, 0, dst.handle if dst else None), "rt_gather_rows")
+            dev.sync()
+            if r == 0:
+                got["image"] = dst.download(np.float32, 4 * w * h).reshape(h, w, 4)
+            lib.rt_comm_destroy(comm)
+        except Exception as e:          # noqa: BLE001 - reported by the main thread
+            errors.append("rank %d: %r" % (r, e))
+
+    threads = [threading.Thread(target=rank, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+        assert not t.is_alive(), "a rank did not come back from the collective"
+    assert not errors, errors
+    assert got["image"].tobytes() == image.tobytes()
