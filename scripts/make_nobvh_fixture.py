@@ -1,7 +1,10 @@
-"""Makes tests/golden/ref_nobvh_lowfreq.npz from the only output image the reference holds, results/NoBVH.png
+"""Makes tests/golden/ref_nobvh_lowfreq.npz and ref_nobvh_detail.npz from the only output image the reference holds, results/NoBVH.png
 (testscene2 without a hierarchy, camera {0,0,0} -> {1,0,0} of src/Settings.h:22-25, a 1922 x 1081 screenshot of the
 1920 x 1080 window): the picture decoded by this repository's own PNG decoder, sRGB -> linear, cropped to 1072 x 1920 and
-averaged over 16 x 16 blocks. Runs in the build container only (needs /root/reference); the fixture is data, not source.
+averaged over 16 x 16 blocks; and, for the pixel-level checks (ref_nobvh_detail.npz): profiles of its luminance - column means of
+eight horizontal bands, row means of 64 vertical bands, from which the place of the picture is found to the pixel - and the
+mean squared Laplacian of the luminance per 16 x 16 block, from which the noise level, hence the number of samples, is
+estimated. Runs in the build container only (needs /root/reference); the fixtures are data, not source.
 
     python scripts/make_nobvh_fixture.py [/root/reference/results/NoBVH.png]
 """
@@ -38,6 +41,17 @@ def main():
     np.savez_compressed(out, rgb=means, source="results/NoBVH.png of the reference, %dx%d, rows 0..%d cols 0..%d, 16x16 block means of linear RGB"
                         % (u8.shape[1], u8.shape[0], ROWS - 1, COLS - 1))
     print("wrote", out, means.shape, "mean linear RGB", means.mean(axis=(0, 1)))
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import compare_nobvh_png as cmp
+    lum = cmp.luminance(lin)
+    cols, rows = cmp.band_profiles(lum)
+    out = os.path.join(ROOT, "tests", "golden", "ref_nobvh_detail.npz")
+    np.savez_compressed(out, column_profiles=cols.astype(np.float32), row_profiles=rows.astype(np.float32),
+                        laplacian_energy=cmp.laplacian_energy(lum).astype(np.float32),
+                        source="results/NoBVH.png of the reference, rows 0..%d cols 0..%d of the screenshot: luminance of linear RGB; column "
+                               "means of 8 horizontal bands, row means of 64 vertical bands, mean squared 4-neighbour Laplacian per 16x16 block"
+                               % (ROWS - 1, COLS - 1))
+    print("wrote", out, cols.shape, rows.shape)
 
 
 if __name__ == "__main__":

@@ -242,3 +242,56 @@ def test_gather_rows_between_two_gpus(device):
         assert not t.is_alive(), "a rank did not come back from the collective"
     assert not errors, errors
     assert got["image"].tobytes() == image.tobytes()
+
+
+def test_reference_screenshot_pins_the_picture_to_the_pixel_and_the_sample_count(device):
+    """results/NoBVH.png of the reference (testscene2 without a hierarchy, 1920 x 1080 window in a 1922 x 1081 screenshot), as
+    the profiles and noise energies of tests/golden/ref_nobvh_detail.npz (scripts/make_nobvh_fixture.py; data, not source).
+    Seeds are unknown, so pixels cannot be compared, but two things can:
+     * where the picture lies. Column means of eight horizontal bands line up with ours at a shift of exactly 0 pixels
+       (correlation of their first differences ~0.5 there, below 0.05 one pixel to either side); row means of 64 vertical
+       bands at -1: the screenshot's last two rows are window border and its first row is the picture's second (the capture
+       is one row off). That pins the flipped, un-centred pixel-to-NDC map (shader/CS_CameraRayGeneration.hlsl:73-77), the
+       column-major reading of the matrices and the camera of src/Settings.h:22-25 to a pixel - no transposed or mirrored
+       variant of them survives a shift of one.
+     * how many samples it holds. The pixel noise (Laplacian energy over squared brightness, median of the 16 x 16
+       blocks) falls with the samples per pixel, the brightness follows the running mean's k / (k + 1) (k sample cycles,
+       shader/CS_GenerateFinalImage.hlsl:28-60). One ray per pixel explains only one of the two: at k = 3, where the brightness
+       fits, the noise is three times the screenshot's; at k = 12, where the noise fits, the picture is a quarter too bright.
+       Three sample cycles of three to four rays per pixel give both: the screenshot's noise lies between those two renders',
+       and their channel means are within 8 % (red and green within 5 %) of its."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("compare_nobvh_png", os.path.join(root, "scripts", "compare_nobvh_png.py"))
+    cmp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cmp)
+    detail = np.load(os.path.join(root, "tests", "golden", "ref_nobvh_detail.npz"))
+    low = np.load(os.path.join(root, "tests", "golden", "ref_nobvh_lowfreq.npz"))["rgb"].astype(np.float64)
+    shot_noise = cmp.relative_noise(detail["laplacian_energy"].astype(np.float64), cmp.luminance(low))
+    shot_mean = low.mean(axis=(0, 1))
+
+    def look(cycles, rpp):
+        img = cmp.render(device, cycles, True, rpp=rpp)
+        rgb = cmp.linear_rgb(img)
+        lum = cmp.luminance(rgb)
+        noise = cmp.relative_noise(cmp.laplacian_energy(lum), cmp.luminance(cmp.low_frequency(img)))
+        return lum, noise, rgb.mean(axis=(0, 1)) / shot_mean
+
+    seen = {}
+    for cycles, rpp in ((3, 1), (12, 1), (3, 3), (3, 4)):
+        lum, noise, ratio = look(cycles, rpp)
+        cols, rows = cmp.band_profiles(lum)
+        cx = cmp.shift_correlation(detail["column_profiles"], cols)
+        cy = cmp.shift_correlation(detail["row_profiles"], rows, smooth=3)
+        print("%2d cycles x %d rays/pixel: x shift %+d (%.3f, next %.3f), y shift %+d (%.3f); noise %.3f (screenshot %.3f); channel means / "
+              "screenshot's %s" % (cycles, rpp, cx.argmax() - 4, cx.max(), np.sort(cx)[-2], cy.argmax() - 4, cy.max(), noise, shot_noise, np.round(ratio, 3)))
+        assert cx.argmax() - 4 == 0 and cx.max() >= 0.3 and np.sort(cx)[-2] <= 0.1, "columns do not line up at zero shift"
+        assert cy.argmax() - 4 == -1 and cy.max() > cy[4] and cy.max() > cy[2], "rows do not line up at the capture's offset of one"
+        seen[(cycles, rpp)] = (noise, ratio)
+    assert seen[(3, 1)][0] > 2.5 * shot_noise and abs(seen[(3, 1)][1][1] - 1.0) < 0.1            # brightness fits, noise does not
+    assert seen[(12, 1)][0] < 1.1 * shot_noise and seen[(12, 1)][1][1] > 1.2                    # noise about right, a quarter too bright
+    assert seen[(3, 4)][0] < shot_noise < seen[(3, 3)][0]
+    for key in ((3, 3), (3, 4)):
+        ratio = seen[key][1]
+        assert np.all(np.abs(ratio - 1.0) <= 0.08) and np.all(np.abs(ratio[:2] - 1.0) <= 0.05), (key, ratio)
