@@ -73,6 +73,7 @@ int rt_device_create(int gpu_index, rt_device** out) {
         t.cost_stride = env("GPURT_COST_STRIDE", 0u);
         t.cost_chord = env("GPURT_COST_CHORD", 2u);
         t.key_passes = env("GPURT_KEY_PASSES", 0u);
+        t.stuck_threshold = env("GPURT_STUCK_THRESHOLD", 0u);
         d->tuning = rt_clamp_tuning(t);
     }
     {

@@ -95,6 +95,7 @@ static inline rt_trace_tuning rt_clamp_tuning(rt_trace_tuning t) {
     if (t.cost_depth > 30u) t.cost_depth = 30u;
     if (t.cost_chord > 2u) t.cost_chord = 2u;
     if (t.key_passes > 3u) t.key_passes = 3u;
+    if (t.stuck_threshold > 64u) t.stuck_threshold = 64u;
     return t;
 }
 

@@ -53,6 +53,7 @@ struct TraceParams {
     uint32_t deal_shift;       // blocks of 2^deal_shift consecutive positions of the ray order are dealt to the queues in turn
     float beyond;              // k_traverse_spatial enters boxes up to reach * beyond
     uint32_t trunk_children;   // node index (reference layout) of the first of the trunk's two children, for hierarchy lv
+    uint32_t stuck_threshold;  // k_traverse_spatial: lanes whose walk is over with leaves still waiting that start a triangle round
     uint32_t walk_hist;        // counting variant of k_traverse_spatial: the counter buffer also has room for steps by depth
     rt_levels lv;
 };
@@ -1220,6 +1221,7 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
 
         // 2. walk until a triangle round is due, a lane has finished its ray, or nobody can walk
         unsigned long long waiting_mask, walking_mask;
+        uint32_t stuck = 0u;
         for (;;) {
             bool empty_step = false;                       // COUNT: this lane's step found none of the four boxes hit
             if (COUNT) { n_turns += 1u; n_steps += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(w <= kFifo - 1u)); }
@@ -1280,12 +1282,15 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
             if (COUNT) n_empty += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(empty_step));
             waiting_mask = __builtin_amdgcn_ballot_w64((w & 15u) != 0u);
             walking_mask = __builtin_amdgcn_ballot_w64(w <= kFifo - 1u);
-            if (!walking_mask || (uint32_t)__popcll(waiting_mask) >= p.leaf_threshold) break;
+            // (lanes whose walk is over wait for a triangle round with nothing else to do: a few of them start one
+            // before the waiting leaves alone would)
+            stuck = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(w > kOver && w < kIdle));
+            if (!walking_mask || (uint32_t)__popcll(waiting_mask) >= p.leaf_threshold || stuck >= p.stuck_threshold) break;
             if ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(w >= kOver && w != kDry)) >= p.refill_threshold) break;
         }
 
         // 3. triangle round once enough lanes have a leaf waiting (or nobody can walk any more)
-        if (waiting_mask && ((uint32_t)__popcll(waiting_mask) >= p.leaf_threshold || !walking_mask)) {
+        if (waiting_mask && ((uint32_t)__popcll(waiting_mask) >= p.leaf_threshold || !walking_mask || stuck >= p.stuck_threshold)) {
             if (COUNT) n_rounds += 1u;
             bool tested = false;                           // COUNT: this lane tests a leaf in this round
             if ((w & 15u) != 0u) {
@@ -1545,6 +1550,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     // (free lanes that start a refill: taking rays from the spatial kernel's stock is cheap, a refill of the others is not)
     p.refill_threshold = tune.refill_threshold ? tune.refill_threshold : (spatial_kernel ? 8u : 16u);
     p.deal_shift = tune.deal_shift;
+    p.stuck_threshold = tune.stuck_threshold ? tune.stuck_threshold : 4u;
     p.beyond = dev->walk_entry_margin;
     const uint32_t deal_block = 1u << p.deal_shift;
     p.queue_chunk = ((((nr + deal_block - 1u) / deal_block) + 7u) / 8u) * deal_block;      // whole blocks, dealt to the eight queues in turn

@@ -135,6 +135,8 @@ typedef struct {
     uint32_t cost_stride;       /* GPURT_COST_STRIDE: every n-th node pair of that depth is probed; 0 = default */
     uint32_t cost_chord;        /* GPURT_COST_CHORD: 1 = estimate from the ray's way through the trunk's box, 0 = probe, 2 = default */
     uint32_t key_passes;        /* GPURT_KEY_PASSES: 8-bit sorting passes over the ray keys, 1 .. 3; 0 = default */
+    uint32_t stuck_threshold;   /* GPURT_STUCK_THRESHOLD: SPATIAL only - lanes whose walk is over but whose leaves still wait that
+                                   start a triangle round before leaf_threshold is reached; 0 = 4 */
 } rt_trace_tuning;
 int rt_device_get_trace_tuning(rt_device* dev, rt_trace_tuning* out);
 int rt_device_set_trace_tuning(rt_device* dev, const rt_trace_tuning* tuning);   /* out-of-range values are clamped */

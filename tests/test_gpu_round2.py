@@ -364,9 +364,9 @@ def test_every_tuning_knob_keeps_the_oracle_image(device, oracle):
     base = capi.TraceTuning()
     capi.check(device.lib.rt_device_get_trace_tuning(device.handle, C.byref(base)), "rt_device_get_trace_tuning")
     knobs = dict(leaf_threshold=5, refill_threshold=40, blocks_per_cu=2, sort_rays=0, deal_shift=9, cost_bits=9, cost_depth=7,
-                 cost_stride=3, cost_chord=0, key_passes=1)
+                 cost_stride=3, cost_chord=0, key_passes=1, stuck_threshold=1)
     cases = [{k: v} for k, v in knobs.items()] + [dict(knobs), dict(cost_chord=1, key_passes=3), dict(leaf_threshold=64, refill_threshold=1),
-                                                            dict(sort_rays=1), dict(sort_rays=2)]
+                                                            dict(sort_rays=1), dict(sort_rays=2), dict(stuck_threshold=64), dict(stuck_threshold=9, leaf_threshold=50)]
     for case in cases:
         t = capi.TraceTuning()
         C.memmove(C.byref(t), C.byref(base), C.sizeof(t))
@@ -376,11 +376,11 @@ def test_every_tuning_knob_keeps_the_oracle_image(device, oracle):
             g = _gpu_render(device, oracle, sc, w, h, cycles, depth, kernel=kernel, tuning=t, keep=ALL)
             _same(g, want, "tuning %s, kernel %d" % (case, kernel))
     # out-of-range values are clamped, not refused
-    t = capi.TraceTuning(*([1000] * 10))
+    t = capi.TraceTuning(*([1000] * 11))
     capi.check(device.lib.rt_device_set_trace_tuning(device.handle, C.byref(t)), "rt_device_set_trace_tuning")
     got = capi.TraceTuning()
     device.lib.rt_device_get_trace_tuning(device.handle, C.byref(got))
-    assert (got.leaf_threshold, got.blocks_per_cu, got.deal_shift, got.cost_bits, got.key_passes, got.sort_rays) == (64, 8, 20, 12, 3, 1)
+    assert (got.leaf_threshold, got.blocks_per_cu, got.deal_shift, got.cost_bits, got.key_passes, got.sort_rays, got.stuck_threshold) == (64, 8, 20, 12, 3, 1, 64)
     device.lib.rt_device_set_trace_tuning(device.handle, C.byref(base))
 
 

@@ -383,10 +383,11 @@ def test_counter_file_of_the_round_travels_with_the_tree():
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    counters, source = bench.load_pmc("c3", "k_traverse_spatial")
-    assert counters is not None and source.startswith("profiles/")
+    counters, source, provenance = bench.load_pmc("c3", "k_traverse_spatial")
+    assert counters is not None and source.startswith("profiles/"), provenance
+    assert provenance["traffic_source_sha"] == provenance["source_sha"] == bench.source_sha()
     assert "FETCH_SIZE" in counters and "WRITE_SIZE" in counters
-    fr = bench.counter_fractions(counters, 4.7e-3)
+    fr = bench.counter_fractions(counters, 2.4e-3)
     assert 0.0 < fr["memory"]["frac"] <= 1.0 and 0.0 < fr["vector"]["frac"] <= 1.0
     ignore = os.path.join(ROOT, ".gpurunignore")
     if os.path.exists(ignore):
