@@ -180,21 +180,23 @@ __global__ __launch_bounds__(256) void k_bounds_finish(uint32_t blocks, const fl
 // The synthetic dynamic workload (no counterpart in the reference, whose scenes are static): triangle i of the
 // base mesh (vertices 3i .. 3i + 2) is moved as a whole by d = 0.25 * sin(2 pi * frac(frame / 32 + 0.618 * i)) along
 // each axis. Everything else of the vertex is copied.
-__global__ __launch_bounds__(256) void k_animate(uint32_t n, uint32_t frame, const rt_vertex* __restrict__ base,
-                                                 rt_vertex* __restrict__ out) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n) return;
-    float ph = (float)frame * 0.03125f + 0.618f * (float)t;
-    ph = ph - floorf(ph);
-    float s, c;
-    rtm::sincos_poly(6.2831853f * ph, &s, &c);
-    const float d = 0.25f * s;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        rt_vertex v = base[3u * t + k];
-        v.position[0] += d; v.position[1] += d; v.position[2] += d;
-        out[3u * t + k] = v;
+// One thread per 16 bytes of the vertex array (a triangle = 144 bytes = nine of them; the first of a vertex's three holds the
+// position and one texture coordinate): every wave reads and writes one contiguous kilobyte, which a thread per triangle
+// copying 48-byte structs 144 bytes apart does not (measured at 50 M triangles: 4.4 ms, 3.3 TB/s).
+__global__ __launch_bounds__(256) void k_animate(uint32_t n, uint32_t frame, const float4* __restrict__ base, float4* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint64_t)n * 9u) return;
+    const uint32_t t = (uint32_t)(i / 9u), part = (uint32_t)(i - (uint64_t)t * 9u);
+    float4 v = base[i];
+    if (part % 3u == 0u) {
+        float ph = (float)frame * 0.03125f + 0.618f * (float)t;
+        ph = ph - floorf(ph);
+        float s, c;
+        rtm::sincos_poly(6.2831853f * ph, &s, &c);
+        const float d = 0.25f * s;
+        v.x += d; v.y += d; v.z += d;
     }
+    out[i] = v;
 }
 
 // Keys of the library's own hierarchy, and every triangle's place in the reference's order: entry r of the
@@ -763,8 +765,12 @@ __device__ __forceinline__ Box next_lane_box(const Box& b, bool exists) {
 // Builds up to eight levels above level k0 from the (up to) 256 level-k0 boxes the workgroup holds in
 // LDS slot order (slot s <-> node blockIdx.x*256 + s of level k0). Same arithmetic as
 // shader/CS_BVHBuild.hlsl:28-47: min/max union, links (first child, second child or 0xffffffff).
+// sparse: of the levels made here only those a later launch or a kernel reads are stored as nodes - every eighth (where
+// k_upsweep takes over) and the two at the top (the trunk and its children); the records of the walk are complete either way.
+__device__ __forceinline__ bool node_level_kept(const rt_levels& lv, uint32_t k) { return !(k & 7u) || k + 2u >= lv.count; }
 __device__ __forceinline__ void upsweep_block(Box mine, uint32_t k0, const rt_levels& lv, rt_aabb* __restrict__ nodes,
-                                              rt_aabb* __restrict__ pairs, float4* __restrict__ quads, float (*s_box)[6]) {
+                                              rt_aabb* __restrict__ pairs, float4* __restrict__ quads, float (*s_box)[6],
+                                              bool sparse = false) {
     const uint32_t tid = threadIdx.x;
     uint32_t cnt = 256u;
     uint32_t k = k0;
@@ -791,7 +797,7 @@ __device__ __forceinline__ void upsweep_block(Box mine, uint32_t k0, const rt_le
             }
             l0 = lv.off[k - 1] + c0;
             l1 = has2 ? l0 + 1u : 0xffffffffu;
-            store_node(nodes, lv.off[k] + gi, mine, l0, l1);
+            if (!sparse || node_level_kept(lv, k)) store_node(nodes, lv.off[k] + gi, mine, l0, l1);
         }
         if ((pairs || quads) && k + 1u < lv.count) {   // same for the whole grid; the trunk is in nobody's record
             if (cnt >= 2u) {
@@ -864,10 +870,13 @@ __device__ const uint32_t d_pair_code[105] = {
 // index of the pair (a, b), a < b, among the 28
 constexpr int pair_index(int a, int b) { return a * 7 - a * (a - 1) / 2 + (b - a - 1); }
 
-// Leaves (shader/CS_BVHBuildLeaves.hlsl:28-63). PACKED reads the packed pair array and the packed
-// triangles and also emits the Morton-ordered triangle copy; otherwise the reference layout
-// (uint4 records, Indices -> Vertices). FUSED continues with up to eight levels in the same launch.
-template <bool PACKED, bool FUSED>
+// Leaves (shader/CS_BVHBuildLeaves.hlsl:28-63). MODE: kLeavesShader reads the reference layout (uint4 records,
+// Indices -> Vertices); kLeavesPacked reads the packed pair array and the packed triangles and also emits the
+// Morton-ordered triangle copy; kLeavesOwn is the packed form for the library's own hierarchy (ref_leaves and cells are
+// given). FUSED continues with up to eight levels in the same launch.
+// sparse_nodes (own hierarchy): leaf nodes and the levels nothing reads are not stored (node_level_kept).
+constexpr int kLeavesShader = 0, kLeavesPacked = 1, kLeavesOwn = 2;
+template <int MODE, bool FUSED>
 __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv, const uint32_t* __restrict__ sorted,
                                                 const uint32_t* __restrict__ indices, const rt_vertex* __restrict__ verts,
                                                 const float4* __restrict__ tris, float4* __restrict__ sorted_tris,
@@ -875,18 +884,28 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
                                                 const uint32_t* __restrict__ cells, uint32_t slots_log2,
                                                 const float4* __restrict__ ref_leaves, float sliver_pad,
                                                 uint2* __restrict__ own_keys, SceneBounds sb, const float* __restrict__ dbounds,
-                                                const uint32_t* __restrict__ axis_map, uint32_t* __restrict__ outliers) {
+                                                const uint32_t* __restrict__ axis_map, uint32_t* __restrict__ outliers,
+                                                uint32_t sparse_nodes) {
+    constexpr bool PACKED = MODE != kLeavesShader, OWN = MODE == kLeavesOwn;
     // Two builds use the extras. The reference's hierarchy, when the library's own is to follow: own_keys receives, for
     // the sorted entries 2g and 2g + 1, (key of the own hierarchy, place in the reference's order) - the corners are in
     // registers here, so the second sort needs no pass of its own over the triangles. The library's own hierarchy:
     // ref_leaves are the reference's leaf records, sorted[] holds (key, place in the reference's order), and a triangle's
     // corners and index slot come from the record of its leaf there (place / 2), one 128-byte line per triangle.
-    __shared__ float s_box[256][6];
-    // with ref_leaves: the sixth 16 bytes of a leaf record hold the places of its two triangles in the reference's order
-    __shared__ uint2 s_rank[PACKED ? 256 : 1];
-    // the workgroup's 256 leaf records are handed over through LDS so that they leave as runs of whole lines
-    // (a lane storing its own record writes 16 bytes to each of 64 different lines per instruction: half the rate)
-    __shared__ float4 s_tri[PACKED ? 256 * 6 : 1];      // (six per lane while the triangles of a group change places)
+    // One block of LDS, used twice: first the workgroup's 256 leaf records are handed over through it so that they leave as
+    // runs of whole lines (a lane storing its own record writes 16 bytes to each of 64 different lines per instruction:
+    // half the rate) - five float4 per lane, six while the triangles of a group change places (own hierarchy) -, then the
+    // up-sweep's boxes (its first barrier comes after the last read of the records). Less LDS = more workgroups per CU,
+    // which is what hides the latency of the gathers.
+    constexpr uint32_t kGroupStride = 25u;
+    constexpr uint32_t kTriWords = OWN ? 64u * kGroupStride : (PACKED ? 256u * 5u : 1u);
+    __shared__ float4 s_raw[kTriWords * 16u > 256u * 24u ? kTriWords : 256u * 24u / 16u];
+    float4* s_tri = s_raw;
+    float (*s_box)[6] = reinterpret_cast<float (*)[6]>(s_raw);
+    // own hierarchy: the sixth 16 bytes of a leaf record hold the places of its two triangles in the reference's order
+    uint2* s_rank = reinterpret_cast<uint2*>(s_raw + 256u * 5u);      // (behind the records; the groups of the pairing search are done with by then)
+    static_assert(!OWN || 256u * 5u + 256u / 2u <= kTriWords, "records and ranks fit where the groups were");
+    __shared__ uint32_t s_group[OWN ? 64 : 1];          // per group of four slots: its triangles, then the pairing chosen for them
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t leaves = (num_prims + 1u) / 2u;
     Box b;
@@ -897,7 +916,7 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
     // triangles first + 2j and first + 2j + 1 of its cell, j = its place among the cell's slots, or nothing
     uint32_t r0 = 2u * g;
     bool have = g < leaves, two = (2u * g + 1u) < num_prims;
-    if (cells && g < leaves) {
+    if (OWN && g < leaves) {
         const uint32_t wshift = slots_log2 - cells[0];
         const uint32_t c = g >> wshift, j = g & ((1u << wshift) - 1u);
         const uint32_t first = cells[RT_CELLS_START + c], count = cells[RT_CELLS_START + c + 1u] - first;
@@ -913,7 +932,7 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
         constexpr int STRIDE = PACKED ? 2 : 4;
         ci0 = sorted[(size_t)r0 * STRIDE + 1];
         if (two) ci1 = sorted[(size_t)(r0 + 1u) * STRIDE + 1];
-        if (PACKED && ref_leaves) {
+        if (OWN) {
             place0 = ci0; place1 = two ? ci1 : 0xffffffffu;
             // one half of an interleaved record (leaf_triangle_record): corners into corner[K .. K + 2], index slot into CI
 #define RT_REF_TRIANGLE(PLACE, K, CI)                                                                                          \
@@ -930,7 +949,7 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
             if (two) RT_REF_TRIANGLE(place1, 3, ci1)
 #undef RT_REF_TRIANGLE
         }
-        if (!(PACKED && ref_leaves)) {
+        if (!OWN) {
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 if (i < 3 || two) {
@@ -945,12 +964,16 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
             }
         }
     }
-    if (PACKED && ref_leaves && cells && slots_log2 - cells[0] >= 2u) {       // same for the whole grid
+    if (OWN && slots_log2 - cells[0] >= 2u) {       // same for the whole grid
         // The library's own hierarchy: the eight triangles of four neighbouring leaf slots (one record of the walk) are
         // paired anew by surface area (see PairTable). The lanes of the four slots hand their triangles over through LDS,
         // each works out the best matching of the eight, and takes the two triangles of its place in it.
         // A group's triangles fill its places from the front; the last one of an odd number stays alone where it is.
-        float4* mine = s_tri + 6u * threadIdx.x;
+        // The search runs in ONE of the workgroup's four waves, a lane per group of eight triangles: the instruction sequence
+        // (a thousand vector instructions) is then issued once per 64 groups instead of once per 16, and the wave that runs
+        // it changes with the workgroup, so that the four SIMDs of a CU share it. (Groups are kGroupStride float4 apart:
+        // 24 hold the triangles, the 25th spreads the lanes' reads over the LDS banks.)
+        float4* mine = s_tri + kGroupStride * (threadIdx.x >> 2) + 6u * (threadIdx.x & 3u);
         mine[0] = make_float4(corner[0][0], corner[0][1], corner[0][2], __uint_as_float(ci0));
         mine[1] = make_float4(corner[1][0], corner[1][1], corner[1][2], __uint_as_float(place0));
         mine[2] = make_float4(corner[2][0], corner[2][1], corner[2][2], 0.0f);
@@ -959,57 +982,63 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
         mine[5] = make_float4(corner[5][0], corner[5][1], corner[5][2], 0.0f);
         const unsigned long long first_mask = __builtin_amdgcn_ballot_w64(have), second_mask = __builtin_amdgcn_ballot_w64(have && two);
         const uint32_t quad = threadIdx.x & 60u;
-        const uint32_t there = (uint32_t)__popcll((first_mask >> quad) & 15ull) + (uint32_t)__popcll((second_mask >> quad) & 15ull);
-        const uint32_t paired = there & ~1u;           // triangles that take part
+        if (!(threadIdx.x & 3u))            // triangles of the group
+            s_group[threadIdx.x >> 2] = (uint32_t)__popcll((first_mask >> quad) & 15ull) + (uint32_t)__popcll((second_mask >> quad) & 15ull);
         __syncthreads();
-        uint32_t code = kPairs.code[0];
-        if (paired >= 4u) {
-            const float4* group = s_tri + 6u * (threadIdx.x & ~3u);
-            float area[28];
-            {
-                float mn[8][3], mx[8][3];
+        if ((threadIdx.x >> 6) == (blockIdx.x & 3u)) {
+            const uint32_t lane = threadIdx.x & 63u;
+            const uint32_t paired = s_group[lane] & ~1u;           // triangles that take part
+            uint32_t code = kPairs.code[0];
+            if (paired >= 4u) {
+                const float4* group = s_tri + kGroupStride * lane;
+                float area[28];
+                {
+                    float mn[8][3], mx[8][3];
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float4 a = group[3 * i], b2 = group[3 * i + 1], c = group[3 * i + 2];
-                    mn[i][0] = fminf(fminf(a.x, b2.x), c.x); mn[i][1] = fminf(fminf(a.y, b2.y), c.y); mn[i][2] = fminf(fminf(a.z, b2.z), c.z);
-                    mx[i][0] = fmaxf(fmaxf(a.x, b2.x), c.x); mx[i][1] = fmaxf(fmaxf(a.y, b2.y), c.y); mx[i][2] = fmaxf(fmaxf(a.z, b2.z), c.z);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-#pragma unroll
-                    for (int j = i + 1; j < 8; j++) {
-                        const float ex = fmaxf(mx[i][0], mx[j][0]) - fminf(mn[i][0], mn[j][0]);
-                        const float ey = fmaxf(mx[i][1], mx[j][1]) - fminf(mn[i][1], mn[j][1]);
-                        const float ez = fmaxf(mx[i][2], mx[j][2]) - fminf(mn[i][2], mn[j][2]);
-                        // a pair of triangles that take part costs its box's surface; pairs of the others cost nothing, so
-                        // that they stay together behind; mixed pairs are out
-                        area[pair_index(i, j)] = (uint32_t)j < paired ? (ex * ey + ey * ez) + ez * ex
-                                                                      : ((uint32_t)i < paired ? __builtin_inff() : 0.0f);
+                    for (int i = 0; i < 8; i++) {
+                        const float4 a = group[3 * i], b2 = group[3 * i + 1], c = group[3 * i + 2];
+                        mn[i][0] = fminf(fminf(a.x, b2.x), c.x); mn[i][1] = fminf(fminf(a.y, b2.y), c.y); mn[i][2] = fminf(fminf(a.z, b2.z), c.z);
+                        mx[i][0] = fmaxf(fmaxf(a.x, b2.x), c.x); mx[i][1] = fmaxf(fmaxf(a.y, b2.y), c.y); mx[i][2] = fmaxf(fmaxf(a.z, b2.z), c.z);
                     }
-            }
-            float best = __builtin_inff();
-            uint32_t best_k = 0u;
 #pragma unroll
-            for (int k = 0; k < 105; k++) {
-                const float cost = (area[pair_index(kPairs.item[k][0], kPairs.item[k][1])] + area[pair_index(kPairs.item[k][2], kPairs.item[k][3])]) +
-                                   (area[pair_index(kPairs.item[k][4], kPairs.item[k][5])] + area[pair_index(kPairs.item[k][6], kPairs.item[k][7])]);
-                if (cost < best) { best = cost; best_k = (uint32_t)k; }
+                    for (int i = 0; i < 8; i++)
+#pragma unroll
+                        for (int j = i + 1; j < 8; j++) {
+                            const float ex = fmaxf(mx[i][0], mx[j][0]) - fminf(mn[i][0], mn[j][0]);
+                            const float ey = fmaxf(mx[i][1], mx[j][1]) - fminf(mn[i][1], mn[j][1]);
+                            const float ez = fmaxf(mx[i][2], mx[j][2]) - fminf(mn[i][2], mn[j][2]);
+                            // a pair of triangles that take part costs its box's surface; pairs of the others cost nothing, so
+                            // that they stay together behind; mixed pairs are out
+                            area[pair_index(i, j)] = (uint32_t)j < paired ? (ex * ey + ey * ez) + ez * ex
+                                                                          : ((uint32_t)i < paired ? __builtin_inff() : 0.0f);
+                        }
+                }
+                float best = __builtin_inff();
+                uint32_t best_k = 0u;
+#pragma unroll
+                for (int k = 0; k < 105; k++) {
+                    const float cost = (area[pair_index(kPairs.item[k][0], kPairs.item[k][1])] + area[pair_index(kPairs.item[k][2], kPairs.item[k][3])]) +
+                                       (area[pair_index(kPairs.item[k][4], kPairs.item[k][5])] + area[pair_index(kPairs.item[k][6], kPairs.item[k][7])]);
+                    if (cost < best) { best = cost; best_k = (uint32_t)k; }
+                }
+                code = d_pair_code[best_k];
             }
-            code = d_pair_code[best_k];
+            s_group[lane] = code;
         }
-        if (have) {
+        __syncthreads();
+        const uint32_t code = s_group[threadIdx.x >> 2];
+        {   // (every lane: a slot without triangles reads back the zeros it wrote, which costs no branch and lets the
+            // corners leave their registers while the search runs)
             const uint32_t at = 2u * (threadIdx.x & 3u);
-            const float4* t0 = s_tri + 6u * (threadIdx.x & ~3u) + 3u * ((code >> (3u * at)) & 7u);
-            const float4* t1 = s_tri + 6u * (threadIdx.x & ~3u) + 3u * ((code >> (3u * at + 3u)) & 7u);
+            const float4* t0 = s_tri + kGroupStride * (threadIdx.x >> 2) + 3u * ((code >> (3u * at)) & 7u);
+            const float4* t1 = s_tri + kGroupStride * (threadIdx.x >> 2) + 3u * ((code >> (3u * at + 3u)) & 7u);
             const float4 a0 = t0[0], b0 = t0[1], c0 = t0[2], a1 = t1[0], b1 = t1[1], c1 = t1[2];
             corner[0][0] = a0.x; corner[0][1] = a0.y; corner[0][2] = a0.z; ci0 = __float_as_uint(a0.w);
             corner[1][0] = b0.x; corner[1][1] = b0.y; corner[1][2] = b0.z; place0 = __float_as_uint(b0.w);
             corner[2][0] = c0.x; corner[2][1] = c0.y; corner[2][2] = c0.z;
-            if (two) {
-                corner[3][0] = a1.x; corner[3][1] = a1.y; corner[3][2] = a1.z; ci1 = __float_as_uint(a1.w);
-                corner[4][0] = b1.x; corner[4][1] = b1.y; corner[4][2] = b1.z; place1 = __float_as_uint(b1.w);
-                corner[5][0] = c1.x; corner[5][1] = c1.y; corner[5][2] = c1.z;
-            }
+            corner[3][0] = a1.x; corner[3][1] = a1.y; corner[3][2] = a1.z; ci1 = __float_as_uint(a1.w);
+            corner[4][0] = b1.x; corner[4][1] = b1.y; corner[4][2] = b1.z; place1 = __float_as_uint(b1.w);
+            corner[5][0] = c1.x; corner[5][1] = c1.y; corner[5][2] = c1.z;
         }
         __syncthreads();                               // the leaf records below go to the same LDS
     }
@@ -1020,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
             for (int i = 0; i < 6; i++) none[i][0] = none[i][1] = none[i][2] = 0.0f;
             leaf_triangle_record(s_tri + 5u * threadIdx.x, none, ci0, ci1);
         }
-        store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
+        if (!sparse_nodes || lv.count <= 2u) store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
     }
     if (have) {
         if (!two) {                                     // no second triangle: repeat the first
@@ -1032,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
             b.mn[0] = fminf(b.mn[0], corner[i][0]); b.mn[1] = fminf(b.mn[1], corner[i][1]); b.mn[2] = fminf(b.mn[2], corner[i][2]);
             b.mx[0] = fmaxf(b.mx[0], corner[i][0]); b.mx[1] = fmaxf(b.mx[1], corner[i][1]); b.mx[2] = fmaxf(b.mx[2], corner[i][2]);
         }
-        if (PACKED && own_keys) {
+        if (MODE == kLeavesPacked && own_keys) {
             if (dbounds) {
                 sb.mn[0] = dbounds[0]; sb.mn[1] = dbounds[1]; sb.mn[2] = dbounds[2];
                 sb.mx[0] = dbounds[4]; sb.mx[1] = dbounds[5]; sb.mx[2] = dbounds[6];
@@ -1064,7 +1093,7 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
             else own_keys[r0] = make_uint2(key[0], r0);
         }
         if (PACKED) leaf_triangle_record(s_tri + 5u * threadIdx.x, corner, ci0, ci1);
-        if (cells) {
+        if (OWN) {
             // The library's own hierarchy only: room around a sliver. The hit test of a triangle whose altitude is a
             // tiny part of its longest edge is dominated by rounding near its long edges (its determinant is just
             // above the reference's cut-off there), and accepts rays that pass beside the triangle's box; the
@@ -1085,23 +1114,23 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
 #pragma unroll
             for (int a = 0; a < 3; a++) { b.mn[a] -= pad; b.mx[a] += pad; }
         }
-        store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
+        if (!sparse_nodes || lv.count <= 2u) store_node(nodes, 1u + g, b, ci0 | 0x80000000u, ci1 | 0x80000000u);
     }
     if (PACKED) {
         // (an empty slot - cell layout only - is marked: its record is never read, because no ray enters its box,
         // and is not written)
-        s_rank[threadIdx.x] = (ref_leaves && have) ? make_uint2(place0, place1)
-                                                   : make_uint2((cells && !have) ? 0xffffffffu : 0u, 0u);
+        if (OWN) s_rank[threadIdx.x] = have ? make_uint2(place0, place1) : make_uint2(0xffffffffu, 0u);
         __syncthreads();
         const uint32_t first = blockIdx.x * 256u;
 #pragma unroll
         for (uint32_t i = 0; i < 8u; i++) {
             const uint32_t e = i * 256u + threadIdx.x;             // float4 e of the workgroup's 256 x 128 bytes
             const uint32_t leaf = e >> 3, j = e & 7u;
-            if (first + leaf < leaves && s_rank[leaf].x != 0xffffffffu)
+            const uint2 rank = OWN ? s_rank[leaf] : make_uint2(0u, 0u);
+            if (first + leaf < leaves && rank.x != 0xffffffffu)
                 sorted_tris[RT_LEAF_STRIDE * (size_t)first + e] =
                     j < 5u ? s_tri[5u * leaf + j]
-                           : (j == 5u ? make_float4(__uint_as_float(s_rank[leaf].x), __uint_as_float(s_rank[leaf].y), 0.0f, 0.0f)
+                           : (j == 5u ? make_float4(__uint_as_float(rank.x), __uint_as_float(rank.y), 0.0f, 0.0f)
                                       : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         }
     }
@@ -1113,7 +1142,7 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t num_prims, rt_levels lv
             if (quads && quad_level(lv, 0u)) store_quad_pair(quads, lv, 0u, g >> 1, b, other);
         }
     }
-    if (FUSED) upsweep_block(b, 0u, lv, nodes, pairs, quads, s_box);
+    if (FUSED) upsweep_block(b, 0u, lv, nodes, pairs, quads, s_box, sparse_nodes != 0u);
 }
 
 // The outliers of a build (RT_CELLS_OUTLIERS) as leaf records for k_traverse_spatial: in ascending order of their places in
@@ -1159,7 +1188,7 @@ __global__ __launch_bounds__(64) void k_outlier_leaves(const uint32_t* __restric
 
 // continues the up-sweep from level k0 (already in memory), eight levels per launch
 __global__ __launch_bounds__(256) void k_upsweep(uint32_t k0, rt_levels lv, rt_aabb* __restrict__ nodes,
-                                                 rt_aabb* __restrict__ pairs, float4* __restrict__ quads) {
+                                                 rt_aabb* __restrict__ pairs, float4* __restrict__ quads, uint32_t sparse_nodes) {
     __shared__ float s_box[256][6];
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     Box b;
@@ -1170,7 +1199,7 @@ __global__ __launch_bounds__(256) void k_upsweep(uint32_t k0, rt_levels lv, rt_a
         float4 lo = p[0], hi = p[1];
         b.mn[0] = lo.x; b.mn[1] = lo.y; b.mn[2] = lo.z; b.mx[0] = lo.w; b.mx[1] = hi.x; b.mx[2] = hi.y;
     }
-    upsweep_block(b, k0, lv, nodes, pairs, quads, s_box);
+    upsweep_block(b, k0, lv, nodes, pairs, quads, s_box, sparse_nodes != 0u);
 }
 
 // one level, reference parameters (shader/CS_BVHBuild.hlsl:25-48)
@@ -1295,11 +1324,36 @@ int rt_private_copy_from_reference(rt_device* dev, uint32_t num_prims, const rt_
     return rt_launch_status();
 }
 
+// Leaves and levels of the library's own hierarchy over the slots, cells and sorted (key, place) pairs of the accel's last
+// build, corners from the reference's leaf records. all_nodes: every level is also stored as nodes in the reference's
+// layout (what the sibling-pair records are derived from); otherwise only the levels something reads (node_level_kept) -
+// the walk itself reads the four-grandchildren records and the leaf records, and those are a third less to write.
+static void own_leaves_and_levels(rt_accel* a, bool all_nodes) {
+    hipStream_t s = a->dev->stream;
+    const uint32_t slots = rt_spatial_slots(a->num_prims);
+    uint32_t slots_log2 = 0u;
+    while ((1u << slots_log2) < slots) slots_log2++;
+    const rt_levels& sl = a->sp_lv;
+    const uint32_t sparse = all_nodes ? 0u : 1u;
+    hipLaunchKernelGGL((k_leaves<kLeavesOwn, true>), dim3(div_up(slots, 256u)), dim3(256), 0, s, 2u * slots, sl, (const uint32_t*)a->sp_sorted,
+                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads,
+                       (const uint32_t*)a->cells, slots_log2, (const float4*)a->sorted_tris, a->dev->walk_sliver_pad, (uint2*)nullptr,
+                       SceneBounds{}, (const float*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, sparse);
+    for (uint32_t k0 = 8u; k0 + 1u < sl.count; k0 += 8u)
+        hipLaunchKernelGGL(k_upsweep, dim3(div_up(sl.n[k0], 256u)), dim3(256), 0, s, k0, sl, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads, sparse);
+    a->sp_nodes_full = all_nodes;
+}
+
 int rt_accel_pairs(rt_accel* a, bool own, const rt_aabb* nodes, const float4** pairs) {
     bool& valid = own ? a->sp_pairs_valid : a->pairs_valid;
     rt_aabb* out = own ? a->sp_pairs : a->pairs;
     *pairs = (const float4*)out;
     if (valid) return RT_OK;
+    // (a build leaves the own hierarchy's nodes incomplete, because nothing on the default path reads them: here they are needed)
+    if (own && !a->sp_nodes_full) {
+        if (!a->sp_built || !a->sp_sorted) return RT_ERR_INVALID_ARGUMENT;
+        own_leaves_and_levels(a, true);
+    }
     rt_levels lv;
     if (own) lv = a->sp_lv;
     else if (!rt_make_levels(a->num_prims, &lv)) return RT_ERR_TOO_FEW_PRIMITIVES;
@@ -1428,11 +1482,11 @@ int rt_bvh_build_leaves(rt_device* dev, const rt_bvh_info* info, const rt_buffer
     lv.count = 0;
     dev->missed_valid = false;          // a new hierarchy: rays that missed the old scene may hit this one,
     dev->keys_ready = false;            // and ray keys made for the old trunk's box are not this one's
-    hipLaunchKernelGGL((k_leaves<false, false>), dim3(div_up(leaves, 256u)), dim3(256), 0, dev->stream, n, lv,
+    hipLaunchKernelGGL((k_leaves<kLeavesShader, false>), dim3(div_up(leaves, 256u)), dim3(256), 0, dev->stream, n, lv,
                        (const uint32_t*)morton_codes->ptr, (const uint32_t*)indices->ptr, (const rt_vertex*)vertices->ptr,
                        (const float4*)nullptr, (float4*)nullptr, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, (float4*)nullptr,
                        (const uint32_t*)nullptr, 0u, (const float4*)nullptr, 0.0f, (uint2*)nullptr, SceneBounds{}, (const float*)nullptr,
-                       (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
     return rt_launch_status();
 }
 
@@ -1469,6 +1523,7 @@ int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out) {
     a->outlier_leaves = nullptr;
     a->pairs_valid = a->sp_pairs_valid = false;
     a->sp_built = false;
+    a->sp_nodes_full = false;
     a->built_prims = 0;
     a->sp_sorted = nullptr;
     a->want_spatial = true;
@@ -1634,10 +1689,13 @@ int rt_synthetic_animate(rt_device* dev, uint32_t num_primitives, uint32_t frame
     if (base_vertices->bytes < (size_t)num_primitives * 144u || vertices->bytes < (size_t)num_primitives * 144u)
         return RT_ERR_BUFFER_TOO_SMALL;
     if (!num_primitives) return RT_OK;
+    if (((uintptr_t)base_vertices->ptr | (uintptr_t)vertices->ptr) & 15u) return RT_ERR_INVALID_ARGUMENT;      // moved 16 bytes at a time
     int rc = rt_set_device(dev);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_animate, dim3(div_up(num_primitives, 256u)), dim3(256), 0, dev->stream, num_primitives, frame,
-                       (const rt_vertex*)base_vertices->ptr, (rt_vertex*)vertices->ptr);
+    static_assert(sizeof(rt_vertex) == 48u, "three 16-byte parts per vertex");
+    const uint64_t parts = (uint64_t)num_primitives * 9u;       // < 2^32 * 3: the grid's x dimension holds the workgroups
+    hipLaunchKernelGGL(k_animate, dim3((uint32_t)((parts + 255u) / 256u)), dim3(256), 0, dev->stream, num_primitives, frame,
+                       (const float4*)base_vertices->ptr, (float4*)vertices->ptr);
     return rt_launch_status();
 }
 
@@ -1673,26 +1731,17 @@ int rt_accel_refit(rt_accel* a, rt_buffer* bvh) {
     const SceneBounds none{};           // (scene bounds only enter the keys, which a refit does not make)
     hipLaunchKernelGGL(k_order_from_leaves, dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, (const float4*)a->sorted_tris, order);
     a->pairs_valid = a->sp_pairs_valid = false;
-    hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)order,
+    hipLaunchKernelGGL((k_leaves<kLeavesPacked, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)order,
                        (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr,
                        a->quads, (const uint32_t*)nullptr, 0u, (const float4*)nullptr, 0.0f, (uint2*)nullptr, none, (const float*)nullptr,
-                       (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
     for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
-        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, a->quads);
+        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, a->quads, 0u);
     if (!own) return rt_launch_status();
     // the same outliers as at the last build, from the refitted leaf records
     hipLaunchKernelGGL(k_outlier_leaves, dim3(1), dim3(64), 0, s, (const uint32_t*)a->cells, (const float4*)a->sorted_tris, a->outlier_leaves);
     // the library's own hierarchy: same slots, same pairs of triangles, corners from the leaf records written above
-    const uint32_t slots = rt_spatial_slots(n);
-    uint32_t slots_log2 = 0u;
-    while ((1u << slots_log2) < slots) slots_log2++;
-    const rt_levels& sl = a->sp_lv;
-    hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(slots, 256u)), dim3(256), 0, s, 2u * slots, sl, (const uint32_t*)a->sp_sorted,
-                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads,
-                       (const uint32_t*)a->cells, slots_log2, (const float4*)a->sorted_tris, dev->walk_sliver_pad, (uint2*)nullptr, none,
-                       (const float*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
-    for (uint32_t k0 = 8u; k0 + 1u < sl.count; k0 += 8u)
-        hipLaunchKernelGGL(k_upsweep, dim3(div_up(sl.n[k0], 256u)), dim3(256), 0, s, k0, sl, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads);
+    own_leaves_and_levels(a, false);
     return rt_launch_status();
 }
 
@@ -1737,13 +1786,13 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     const uint32_t leaves = lv.n[0];
     // the pair records are not written here: the traversal kernels that read them have them made on demand
     a->pairs_valid = a->sp_pairs_valid = false;
-    hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)src,
+    hipLaunchKernelGGL((k_leaves<kLeavesPacked, true>), dim3(div_up(leaves, 256u)), dim3(256), 0, s, n, lv, (const uint32_t*)src,
                        (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sorted_tris, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr,
                        a->quads, (const uint32_t*)nullptr, 0u, (const float4*)nullptr, 0.0f, own ? other : (uint2*)nullptr, spb, dbounds,
-                       (const uint32_t*)(a->cells + RT_CELLS_AXIS), a->cells + RT_CELLS_OUTLIERS);
+                       (const uint32_t*)(a->cells + RT_CELLS_AXIS), a->cells + RT_CELLS_OUTLIERS, 0u);
     if (own) hipLaunchKernelGGL(k_outlier_leaves, dim3(1), dim3(64), 0, s, (const uint32_t*)a->cells, (const float4*)a->sorted_tris, a->outlier_leaves);
     for (uint32_t k0 = 8u; k0 + 1u < lv.count; k0 += 8u)
-        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, a->quads);
+        hipLaunchKernelGGL(k_upsweep, dim3(div_up(lv.n[k0], 256u)), dim3(256), 0, s, k0, lv, (rt_aabb*)bvh->ptr, (rt_aabb*)nullptr, a->quads, 0u);
     if (morton_codes)
         hipLaunchKernelGGL(k_expand_keys, dim3(div_up(n, 256u)), dim3(256), 0, s, n, src, (uint4*)morton_codes->ptr);
 
@@ -1763,19 +1812,13 @@ int accel_build(rt_accel* a, const float* scene_min, const float* scene_max, con
     uint32_t slots_log2 = 0u;
     while ((1u << slots_log2) < slots) slots_log2++;
     rt_make_levels(2u * slots, &a->sp_lv);
-    const rt_levels& sl = a->sp_lv;
     RT_HIP(hipMemsetAsync(a->cells, 0, (size_t)RT_CELLS_START * sizeof(uint32_t), s));
     hipLaunchKernelGGL(k_cell_hist, dim3(div_up(n, 256u)), dim3(256), 0, s, n, (const uint2*)sp_src, a->cells);
     hipLaunchKernelGGL(k_cell_sums, dim3((1u << RT_CELL_BITS_MAX) / 512u), dim3(512), 0, s, a->cells);
     hipLaunchKernelGGL(k_cell_choose, dim3(1), dim3(1024), 0, s, a->cells, slots_log2, a->cell_bits_cap);
     hipLaunchKernelGGL(k_cell_starts, dim3(div_up(n, 256u)), dim3(256), 0, s, n, (const uint2*)sp_src, a->cells);
     hipLaunchKernelGGL(k_cell_fill, dim3(256), dim3(256), 0, s, a->cells);
-    hipLaunchKernelGGL((k_leaves<true, true>), dim3(div_up(slots, 256u)), dim3(256), 0, s, 2u * slots, sl, (const uint32_t*)sp_src,
-                       (const uint32_t*)nullptr, (const rt_vertex*)nullptr, a->tris, a->sp_tris, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads,
-                       (const uint32_t*)a->cells, slots_log2, (const float4*)a->sorted_tris, dev->walk_sliver_pad, (uint2*)nullptr, spb,
-                       (const float*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
-    for (uint32_t k0 = 8u; k0 + 1u < sl.count; k0 += 8u)
-        hipLaunchKernelGGL(k_upsweep, dim3(div_up(sl.n[k0], 256u)), dim3(256), 0, s, k0, sl, a->sp_nodes, (rt_aabb*)nullptr, a->sp_quads);
+    own_leaves_and_levels(a, false);
     return rt_launch_status();
 }
 

@@ -218,6 +218,7 @@ struct rt_accel {
     bool want_spatial;         // rt_accel_set_second_hierarchy: builds make the library's own hierarchy
     uint32_t cell_bits_cap;    // ... with leaf slots aligned to Morton cells of at most this many bits
     bool sp_built;             // the last build made it
+    bool sp_nodes_full;        // ... and every level of it is in sp_nodes (builds store only the levels something reads)
     uint32_t built_prims;      // triangles of the last build (0: none yet) - what rt_accel_refit may refit
     uint2* sp_sorted;          // keys_a or keys_b: the own hierarchy's sorted (key, place) pairs of the last build
     rt_levels sp_lv;           // shape of that hierarchy at the last build: rt_spatial_slots(num_prims) leaves, all levels full
