@@ -113,7 +113,9 @@ static inline bool rt_rows_fit(uint32_t first_row, uint32_t num_rows, uint32_t r
 
 // radix sort tiling: 256 threads x RT_SORT_ITEMS keys per workgroup
 #define RT_SORT_THREADS 256
+#ifndef RT_SORT_ITEMS
 #define RT_SORT_ITEMS 8
+#endif
 #define RT_SORT_TILE (RT_SORT_THREADS * RT_SORT_ITEMS)
 
 int rt_sort_workspace(rt_device* dev, uint32_t num_elements);   // grows dev->sort_table as needed
