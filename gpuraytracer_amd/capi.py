@@ -132,6 +132,8 @@ SIGNATURES = {
     "rt_accel_build": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
     "rt_device_set_trace_kernel": (C.c_int, [_P, C.c_int]),
     "rt_device_listed_rays": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    "rt_device_listed_rays_detail": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rt_device_set_listed_split": (C.c_int, [_P, C.c_int]),
     "rt_device_set_slab_division": (C.c_int, [_P, C.c_int]),
     "rt_device_set_drop_missed_rays": (C.c_int, [_P, C.c_int]),
     "rt_device_set_walk_margins": (C.c_int, [_P, C.c_float, C.c_float]),

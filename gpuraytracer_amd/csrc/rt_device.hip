@@ -34,6 +34,9 @@ int rt_device_create(int gpu_index, rt_device** out) {
     d->ray_keys_a = nullptr;
     d->ray_keys_b = nullptr;
     d->listed_rays = nullptr;
+    d->split_cand = nullptr; d->split_count = nullptr; d->listed_again = nullptr;
+    d->listed_seen_host = nullptr; d->listed_seen_dev = nullptr;
+    d->listed_split = 0;
     d->walk_stats = nullptr;
     d->walk_stats_hist = false;
     d->conv_pairs = nullptr;
@@ -75,6 +78,8 @@ int rt_device_create(int gpu_index, rt_device** out) {
         t.key_passes = env("GPURT_KEY_PASSES", 0u);
         t.stuck_threshold = env("GPURT_STUCK_THRESHOLD", 0u);
         d->tuning = rt_clamp_tuning(t);
+        const uint32_t in_parts = env("GPURT_LISTED_SPLIT", 0u);      // rt_device_set_listed_split
+        d->listed_split = in_parts <= 2u ? (int)in_parts : 0;
     }
     {
         hipDeviceProp_t prop;
@@ -109,6 +114,10 @@ int rt_device_destroy(rt_device* dev) {
     if (dev->ray_keys_a) (void)hipFree(dev->ray_keys_a);
     if (dev->ray_keys_b) (void)hipFree(dev->ray_keys_b);
     if (dev->listed_rays) (void)hipFree(dev->listed_rays);
+    if (dev->split_cand) (void)hipFree(dev->split_cand);
+    if (dev->split_count) (void)hipFree(dev->split_count);
+    if (dev->listed_again) (void)hipFree(dev->listed_again);
+    if (dev->listed_seen_host) (void)hipHostFree(dev->listed_seen_host);
     if (dev->missed) (void)hipFree(dev->missed);
     if (dev->conv_pairs) (void)hipFree(dev->conv_pairs);
     if (dev->conv_tris) (void)hipFree(dev->conv_tris);

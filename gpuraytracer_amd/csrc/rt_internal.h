@@ -50,6 +50,13 @@ struct rt_device {
     const void* missed_rays;   // ... whose ray buffer and ray count these were
     uint32_t missed_count;
     bool listed_valid;         // the last trace call ran the SPATIAL kernel, so queue_counter[128] is its list length
+    // A short list is walked in parts (one subtree of the reference's hierarchy per lane, see k_traverse_quad<true>):
+    float4* split_cand;        // [RT_SPLIT_RAYS << 6][RT_SPLIT_CANDIDATES][2] what the parts found, in the order found
+    uint32_t* split_count;     // [RT_SPLIT_RAYS << 6] how many (more than RT_SPLIT_CANDIDATES: the part ran out of room)
+    uint2* listed_again;       // [RT_SPLIT_RAYS] rays with such a part: walked whole after all
+    uint32_t* listed_seen_host;    // host-mapped word: the list length a recent trace call reported (what the next call expects)
+    uint32_t* listed_seen_dev;     // ... the address kernels write it through
+    int listed_split;          // rt_device_set_listed_split: 0 = by expectation, 1 = always in parts, 2 = never
     bool time_traverse;
     hipEvent_t* timing_events;      // [2 * timing_capacity]: start, stop, start, stop, ...
     uint32_t timing_count, timing_capacity;
@@ -110,6 +117,10 @@ static inline bool rt_rows_fit(uint32_t first_row, uint32_t num_rows, uint32_t r
     if (!num_rows) return true;
     return (uint64_t)first_row + (uint64_t)(num_rows - 1u) * row_stride < height;
 }
+
+// listed rays walked in parts: lists up to this length, and the candidates a part can hold
+#define RT_SPLIT_RAYS 512u
+#define RT_SPLIT_CANDIDATES 6u
 
 // radix sort tiling: 256 threads x RT_SORT_ITEMS keys per workgroup
 #define RT_SORT_THREADS 256

@@ -734,17 +734,59 @@ __device__ __forceinline__ float leaf_box_entry(f3 o, f3 inv_d, float lim, float
     return (!(tf < vmax(tn, lim)) && (tn != 1e30f)) ? tn : __builtin_inff();
 }
 
+// ---- a short list of rays, walked in parts ----
+//
+// The rays k_traverse_spatial lists are few - a few dozen of two million on the reference's own room scene - and their
+// walk in the reference's order is long: hundreds of dependent steps, a third of a millisecond for one lane, however
+// few the rays. SPLIT deals such a list out in parts: lane j of a ray walks only the subtree of node j at depth
+// `depth` (up to 64 of them), with the same step, the same list of waiting leaves and the same exact test of a leaf's
+// box - but it cannot know the closest hit the walk would have brought along from the subtrees before it. So it keeps
+// a bound instead that is never below that closest hit, and writes down every triangle that could become the closest
+// hit under ANY incoming value - its candidates, in the order of the walk:
+//  * bound starts at the ray's far end and falls to max(hit distance, entry distance of the leaf's box) with every
+//    candidate. Whatever the closest hit was when the reference's walk came to that triangle, afterwards it is at most
+//    that: if the leaf's box let the ray in before the closest hit, the triangle was tested and the closest hit is at
+//    most its distance; if not, the closest hit was at most the box's entry distance already.
+//  * a leaf is tested if its box lets the ray in before the bound, a triangle noted if its distance is below the bound:
+//    both hold for everything the reference's walk tests and accepts, whose closest hit is at most the bound.
+// k_listed_merge then goes through the parts in order (the order of the subtrees is the order of the walk) and applies
+// the reference's two comparisons to every candidate with the closest hit it has by then - a leaf's triangles are
+// tested if the box's entry distance is below the closest hit before the leaf's first triangle, a hit is kept if it is
+// strictly closer -, which is the reference's walk with the triangles left out that it would have rejected anyway.
+// A part that runs out of room for candidates puts its ray on a second list, which the plain form walks whole.
+struct ListedSplit {
+    uint32_t cap;                       // lists of up to this many rays are walked in parts (0: no list is)
+    uint32_t depth;                     // the parts are the subtrees of the nodes at this depth below the trunk
+    float4* cand;                       // [cap << depth][RT_SPLIT_CANDIDATES][2]
+    uint32_t* cand_count;               // [cap << depth]
+    const uint2* again;                 // plain form: a second list, walked after the first ...
+    const uint32_t* again_count;        // ... of this length (nullptr: none)
+    uint32_t* seen;                     // host-visible word that receives the length of the first list (nullptr: none)
+};
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const float4* __restrict__ rays, const float4* __restrict__ nodes,
                                                        const float4* __restrict__ pairs, const float4* __restrict__ quads,
                                                        const float4* __restrict__ sorted_tris, float4* __restrict__ hit_records,
                                                        uint32_t* __restrict__ hit_ci, uint32_t* __restrict__ queue,
-                                                       const uint2* __restrict__ order, const uint32_t* __restrict__ listed) {
+                                                       const uint2* __restrict__ order, const uint32_t* __restrict__ listed,
+                                                       const ListedSplit split) {
     extern __shared__ uint32_t s_dyn[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     uint32_t num_rays = p.num_rays, queue_chunk = p.queue_chunk;      // (the kernel argument itself stays untouched: in registers)
+    uint32_t first_list = 0u;                                         // plain form with two lists: entries of the first
     if (listed) {
         // the rays are the first *listed entries of order: a list another kernel of the same stream has filled
         num_rays = *listed;
+        if (!SPLIT && split.seen && blockIdx.x == 0u && tid == 0u) *split.seen = num_rays;
+        if (SPLIT) {
+            if (num_rays == 0u || num_rays > split.cap) return;       // (a long list is the plain form's)
+            num_rays <<= split.depth;
+        } else {
+            if (num_rays <= split.cap) num_rays = 0u;                 // (a short list has been walked in parts)
+            first_list = num_rays;
+            if (split.again_count) num_rays += *split.again_count;
+        }
         if (num_rays == 0u) return;
         const uint32_t deal_block = 1u << p.deal_shift;
         queue_chunk = ((((num_rays + deal_block - 1u) >> p.deal_shift) + 7u) / 8u) * deal_block;
@@ -771,6 +813,7 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
     unsigned long long trail = 0ull;
     uint32_t wait_head = 0u;
     uint32_t q = blockIdx.x & 7u, queues_tried = 0u;       // wave-uniform
+    uint32_t noted = 0u;              // SPLIT: candidates of this lane's part so far (ray = number of the part; best.t = the bound)
 
     for (;;) {
         // 1. refill: every lane without a ray takes the next index; one atomic per wave (see k_traverse)
@@ -797,7 +840,9 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
                         const uint32_t slot = mine - q_begin;
                         const uint32_t pos = (((slot >> p.deal_shift) * 8u + q) << p.deal_shift) | (slot & ((1u << p.deal_shift) - 1u));
                         if (pos < num_rays) {
-                            const uint32_t rid = order ? order[pos].y : pos;
+                            uint32_t rid;
+                            if (SPLIT) rid = order[pos >> split.depth].y;
+                            else rid = !order ? pos : (pos < first_list || !split.again_count) ? order[pos].y : split.again[pos - first_list].y;
                             const float4 r0 = rays[2 * (size_t)rid], r1 = rays[2 * (size_t)rid + 1];
                             org = mk(r0.x, r0.y, r0.z); dir = mk(r0.w, r1.x, r1.y);
                             tmin_r = r1.z; tmax_r = r1.w;
@@ -811,6 +856,15 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
                             // the trunk is entered on any box hit
                             bool walk = slab(org, inv_d, tmin_r, tmax_r, root_lo, root_hi) != 1e30f;
                             h = 1u; trail = 0ull;
+                            if (SPLIT) {
+                                // this lane's part: the subtree of node `part` at the parts' depth, if there is such a node
+                                const uint32_t part = pos & ((1u << split.depth) - 1u);
+                                walk = walk && part < p.lv.n[root_level - split.depth];
+                                h = (1u << split.depth) + part;
+                                noted = 0u;
+                                if (walk) { ray = pos; w = 0u; }
+                                else split.cand_count[pos] = 0u;
+                            } else
                             if (walk && odd_first) {
                                 // the trunk's two children, exact boxes, from the nodes in the reference's layout
                                 const float4* c = nodes + 2 * (size_t)p.trunk_children;
@@ -821,7 +875,8 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
                                 h = hit0 ? 2u : 3u;
                                 trail = (hit0 && hit1) ? 8ull : 0ull;
                             }
-                            if (walk) {
+                            if (SPLIT) {
+                            } else if (walk) {
                                 ray = rid; w = 0u;
                             } else {
                                 hit_records[rid] = make_float4(best.t, 0.0f, 0.0f, 0.0f);
@@ -907,7 +962,30 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
                     intersect_leaf(org, dir, l0, l1, l2, l3, l4, h0, h1);
                     const bool may0 = (tmin_r <= h0.t) && (tmax_r > h0.t) && (h0.t < best.t);
                     const bool may1 = (ci1 != 0xffffffffu) && (tmin_r <= h1.t) && (tmax_r > h1.t) && (h1.t < best.t);
-                    if (may0 || may1) {
+                    if (SPLIT) {
+                        if (may0 || may1) {
+                            const float entry = leaf_box_entry(org, inv_d, lim, l0, l1, l2, l3, l4);      // +infinity: the ray passes by
+                            if (entry < best.t) {
+                                float4* mine = split.cand + (size_t)ray * (2u * RT_SPLIT_CANDIDATES);
+                                if (may0) {
+                                    if (noted < RT_SPLIT_CANDIDATES) {
+                                        mine[2u * noted] = make_float4(h0.t, h0.u, h0.v, h0.w);
+                                        mine[2u * noted + 1u] = make_float4(__uint_as_float(ci0), entry, __uint_as_float(2u * e.x), 0.0f);
+                                    }
+                                    noted++;
+                                    best.t = fminf(best.t, fmaxf(h0.t, entry));
+                                }
+                                if (may1 && h1.t < best.t) {
+                                    if (noted < RT_SPLIT_CANDIDATES) {
+                                        mine[2u * noted] = make_float4(h1.t, h1.u, h1.v, h1.w);
+                                        mine[2u * noted + 1u] = make_float4(__uint_as_float(ci1), entry, __uint_as_float(2u * e.x + 1u), 0.0f);
+                                    }
+                                    noted++;
+                                    best.t = fminf(best.t, fmaxf(h1.t, entry));
+                                }
+                            }
+                        }
+                    } else if (may0 || may1) {
                         const bool wanted = leaf_box_passes(org, inv_d, lim, best.t, l0, l1, l2, l3, l4);
                         check_hit_select(wanted, h0, tmin_r, tmax_r, ci0, best, best_ci);
                         check_hit_select(wanted && ci1 != 0xffffffffu, h1, tmin_r, tmax_r, ci1, best, best_ci);
@@ -918,10 +996,57 @@ __global__ __launch_bounds__(256) void k_traverse_quad(TraceParams p, const floa
 
         // 4. a finished ray leaves its closest hit behind and frees the lane
         if (w == kOver) {
-            hit_records[ray] = make_float4(best.t, best.u, best.v, best.w);
-            hit_ci[ray] = best_ci;
+            if (SPLIT) {
+                split.cand_count[ray] = noted;
+            } else {
+                hit_records[ray] = make_float4(best.t, best.u, best.v, best.w);
+                hit_ci[ray] = best_ci;
+            }
             w = kIdle;
         }
+    }
+}
+
+// The parts of every ray of a short list, put together (see ListedSplit): one lane per ray. A ray one of whose parts
+// ran out of room goes on the second list (again / again_count), for the plain form of the walk.
+__global__ __launch_bounds__(256) void k_listed_merge(const float4* __restrict__ rays, const uint2* __restrict__ order,
+                                                      const uint32_t* __restrict__ listed, const ListedSplit split,
+                                                      float4* __restrict__ hit_records, uint32_t* __restrict__ hit_ci,
+                                                      uint2* __restrict__ again, uint32_t* __restrict__ again_count) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t count = *listed;
+    if (split.seen && i == 0u) *split.seen = count;
+    if (count > split.cap || i >= count) return;
+    const uint32_t rid = order[i].y;
+    const uint32_t parts = 1u << split.depth, first = i << split.depth;
+    Hit best;
+    best.t = rays[2 * (size_t)rid + 1].w; best.u = 0.0f; best.v = 0.0f; best.w = 0.0f;      // the ray's far end: no hit yet
+    uint32_t best_ci = 0u;
+    bool complete = true;
+    uint32_t leaf = 0xffffffffu;          // the leaf the last candidate belonged to, and whether the walk tests its triangles
+    bool open = false;
+    for (uint32_t part = 0u; part < parts; part++) {
+        const uint32_t n = split.cand_count[first + part];
+        if (n > RT_SPLIT_CANDIDATES) { complete = false; break; }
+        const float4* c = split.cand + (size_t)(first + part) * (2u * RT_SPLIT_CANDIDATES);
+        for (uint32_t k = 0u; k < n; k++) {
+            const float4 hit = c[2u * k], more = c[2u * k + 1u];
+            const uint32_t place = __float_as_uint(more.z);
+            if ((place >> 1) != leaf) {                               // shader/CS_TraceRays.hlsl:196: the box, against the closest hit so far
+                leaf = place >> 1;
+                open = more.y < best.t;
+            }
+            if (open && hit.x < best.t) {                             // shader/CS_TraceRays.hlsl:110: strictly closer
+                best.t = hit.x; best.u = hit.y; best.v = hit.z; best.w = hit.w;
+                best_ci = __float_as_uint(more.x);
+            }
+        }
+    }
+    if (complete) {
+        hit_records[rid] = make_float4(best.t, best.u, best.v, best.w);
+        hit_ci[rid] = best_ci;
+    } else {
+        again[atomicAdd(again_count, 1u)] = make_uint2(0u, rid);
     }
 }
 
@@ -1031,8 +1156,12 @@ __device__ __forceinline__ void walk_hits_finish(WalkHits& s, uint32_t ray, floa
     hit_ci[ray] = s.best_ci;
     // the closest hit lies before the entry of its leaf's box and another hit lies in between: which of
     // them the reference keeps depends on the order it meets them in
+    const bool during_walk = s.again;       // (a closer hit behind a box entry beyond reach; counted apart in flag_count[2])
     if (s.best_rank != 0xffffffffu && s.reach > s.best.t && s.runner_up <= s.reach) s.again = true;
-    if (s.again) flagged[atomicAdd(flag_count, 1u)] = make_uint2(0u, ray);
+    if (s.again) {
+        flagged[atomicAdd(flag_count, 1u)] = make_uint2(0u, ray);
+        if (during_walk) atomicAdd(flag_count + 2, 1u);
+    }
 }
 
 template <bool COUNT>
@@ -1466,6 +1595,25 @@ int trace_workspace(rt_device* dev, uint32_t num_rays) {
     return RT_OK;
 }
 
+// what a short list of rays is walked in parts with (ListedSplit), and the host-visible word the list lengths are reported in
+int split_workspace(rt_device* dev) {
+    if (dev->split_cand) return RT_OK;
+    hipError_t e = hipSuccess;
+    if (!dev->listed_seen_host) {
+        e = hipHostMalloc((void**)&dev->listed_seen_host, sizeof(uint32_t), hipHostMallocMapped);
+        if (e == hipSuccess) {
+            *dev->listed_seen_host = 0u;
+            e = hipHostGetDevicePointer((void**)&dev->listed_seen_dev, dev->listed_seen_host, 0);
+        }
+    }
+    const size_t parts = (size_t)RT_SPLIT_RAYS << 6;
+    if (e == hipSuccess && !dev->split_count) e = hipMalloc((void**)&dev->split_count, parts * sizeof(uint32_t));
+    if (e == hipSuccess && !dev->listed_again) e = hipMalloc((void**)&dev->listed_again, (size_t)RT_SPLIT_RAYS * sizeof(uint2));
+    if (e == hipSuccess) e = hipMalloc((void**)&dev->split_cand, parts * 2u * RT_SPLIT_CANDIDATES * sizeof(float4));
+    if (e != hipSuccess) return e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP_BASE + (int)e;
+    return RT_OK;
+}
+
 // buffers of the private hierarchy copy made for trace calls without an accel
 int convert_workspace(rt_device* dev, uint32_t num_prims, const rt_levels& lv) {
     if (num_prims <= dev->conv_capacity) return RT_OK;
@@ -1730,12 +1878,41 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
         if (dev->walk_stats) RT_LAUNCH_SPATIAL(true);
         else RT_LAUNCH_SPATIAL(false);
 #undef RT_LAUNCH_SPATIAL
-        hipLaunchKernelGGL(k_traverse_quad, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in, nodes, pairs, quads,
-                           st, dev->hit_records, dev->hit_ci, dev->queue_counter + 64, (const uint2*)dev->listed_rays,
-                           (const uint32_t*)listed);
+        // The listed rays. A short list is walked in parts (k_traverse_quad<true>, k_listed_merge) - but only where a list
+        // is expected at all: the two extra launches cost a few microseconds each even when they find nothing to do, and
+        // most scenes never list a ray. What to expect is what a recent call on this device saw (the kernels leave the
+        // length of their list in a word of host memory; it may be a call or two old, which only ever costs time: the
+        // plain form alone is complete for any list).
+        rc = split_workspace(dev);
+        if (rc) return rc;
+        ListedSplit split;
+        split.cap = 0u; split.depth = 0u; split.cand = nullptr; split.cand_count = nullptr;
+        split.again = nullptr; split.again_count = nullptr;
+        split.seen = dev->listed_seen_dev;
+        const uint32_t ref_root_level = p.lv.count - 1u;
+        const bool in_parts = dev->listed_split == 1 || (dev->listed_split == 0 && *(volatile uint32_t*)dev->listed_seen_host != 0u);
+        if (in_parts) {
+            // the parts: subtrees of the nodes at the deepest depth up to 6 that the walk's steps pass through (every second
+            // one, from the trunk or from its children) and that has records of four grandchildren below it
+            uint32_t depth = ref_root_level & 1u;
+            while (depth + 2u <= 6u && depth + 2u + 2u <= ref_root_level) depth += 2u;
+            split.cap = RT_SPLIT_RAYS; split.depth = depth;
+            split.cand = dev->split_cand; split.cand_count = dev->split_count;
+            const uint32_t part_groups = min(groups, (RT_SPLIT_RAYS << depth) / 256u);
+            hipLaunchKernelGGL((k_traverse_quad<true>), dim3(part_groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in, nodes,
+                               pairs, quads, st, dev->hit_records, dev->hit_ci, dev->queue_counter + 192, (const uint2*)dev->listed_rays,
+                               (const uint32_t*)listed, split);
+            hipLaunchKernelGGL(k_listed_merge, dim3(RT_SPLIT_RAYS / 256u), block, 0, s, ray_in, (const uint2*)dev->listed_rays,
+                               (const uint32_t*)listed, split, dev->hit_records, dev->hit_ci, dev->listed_again, dev->queue_counter + 131);
+            split.again = dev->listed_again; split.again_count = dev->queue_counter + 131;
+            split.seen = nullptr;                 // (the merge kernel has reported the length)
+        }
+        hipLaunchKernelGGL((k_traverse_quad<false>), dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in, nodes, pairs,
+                           quads, st, dev->hit_records, dev->hit_ci, dev->queue_counter + 64, (const uint2*)dev->listed_rays,
+                           (const uint32_t*)listed, split);
     } else if (quad_kernel && offsets_fit && p.lv.count >= 3u && quads)
-        hipLaunchKernelGGL(k_traverse_quad, dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in, nodes, pairs, quads,
-                           st, dev->hit_records, dev->hit_ci, dev->queue_counter, order, (const uint32_t*)live);
+        hipLaunchKernelGGL((k_traverse_quad<false>), dim3(groups), block, (size_t)kFifo * 512u * sizeof(uint32_t), s, p, ray_in, nodes, pairs,
+                           quads, st, dev->hit_records, dev->hit_ci, dev->queue_counter, order, (const uint32_t*)live, ListedSplit{});
     else RT_LAUNCH_TRAVERSE(false, false);
 #undef RT_LAUNCH_TRAVERSE
     if (timing) {
@@ -1845,6 +2022,26 @@ int rt_device_listed_rays(rt_device* dev, uint32_t* count) {
     if (rc) return rc;
     RT_HIP(hipMemcpyAsync(count, dev->queue_counter + 128, sizeof(uint32_t), hipMemcpyDeviceToHost, dev->stream));
     RT_HIP(hipStreamSynchronize(dev->stream));
+    return RT_OK;
+}
+
+int rt_device_set_listed_split(rt_device* dev, int mode) {
+    if (!dev || mode < 0 || mode > 2) return RT_ERR_INVALID_ARGUMENT;
+    dev->listed_split = mode;
+    return RT_OK;
+}
+
+int rt_device_listed_rays_detail(rt_device* dev, uint32_t* total, uint32_t* during_walk, uint32_t* whole_after_parts) {
+    if (!dev || !total || !during_walk || !whole_after_parts) return RT_ERR_INVALID_ARGUMENT;
+    *total = *during_walk = *whole_after_parts = 0u;
+    if (!dev->queue_counter || !dev->listed_valid) return RT_OK;
+    int rc = rt_set_device(dev);
+    if (rc) return rc;
+    // list length, live count of drop-missed-rays mode, listed during the walk, rays whose parts ran out of room
+    uint32_t words[4] = {0u, 0u, 0u, 0u};
+    RT_HIP(hipMemcpyAsync(words, dev->queue_counter + 128, sizeof(words), hipMemcpyDeviceToHost, dev->stream));
+    RT_HIP(hipStreamSynchronize(dev->stream));
+    *total = words[0]; *during_walk = words[2]; *whole_after_parts = words[3];
     return RT_OK;
 }
 

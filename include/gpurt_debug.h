@@ -26,6 +26,16 @@ int rt_device_set_walk_margins(rt_device* dev, float entry_margin, float sliver_
 /* Instrumentation (no counterpart in the reference): how many rays of the device's last trace call the SPATIAL
  * kernel handed to the walk in the reference's order (0 after a call with another kernel). Waits for the stream. */
 int rt_device_listed_rays(rt_device* dev, uint32_t* count);
+/* ... how many of them were listed while they were walked (a closer hit whose leaf box in the reference's hierarchy
+ * lets the ray in only beyond the reach of the closest hit so far) rather than at the end (another hit between the
+ * closest hit and the entry of its leaf's box), and - where the list was walked in parts (rt_device_set_listed_split) -
+ * how many had a part that ran out of room for its candidates and were walked whole after all. */
+int rt_device_listed_rays_detail(rt_device* dev, uint32_t* total, uint32_t* during_walk, uint32_t* whole_after_parts);
+/* Test switch (no counterpart in the reference): how the listed rays are walked in the reference's order. A short list
+ * (up to 512 rays) can be dealt out in parts - one subtree of the reference's hierarchy per lane, put together afterwards,
+ * same result - which takes two more kernel launches; 0 (default): only after a recent trace call on this device has
+ * listed rays, 1: always, 2: never (one lane per listed ray). */
+int rt_device_set_listed_split(rt_device* dev, int mode);
 /* Instrumentation (no counterpart in the reference): while a 32-byte buffer is set, every launch of the SPATIAL kernel
  * adds {steps (one 64-byte record read and four boxes tested each), steps that hit none of the four, leaves whose
  * triangles were tested, turns of the waves' walking loops | triangle rounds of the waves << 32} as four uint64 to

@@ -113,6 +113,7 @@ def run(dev, cases, seed, w=256, h=144, calls=4, depth=4, verbose=True, against_
     rng = np.random.RandomState(seed)
     bad = 0
     total_listed = 0
+    run.in_parts = run.whole_after_parts = 0      # rays of lists short enough to be walked in parts; of them, walked whole after all
     t0 = time.time()
     for case in range(cases):
         sc, kind, n = random_scene(rng)
@@ -129,9 +130,12 @@ def run(dev, cases, seed, w=256, h=144, calls=4, depth=4, verbose=True, against_
             for _ in range(calls):
                 p.render(1)
                 if kernel == 3:
-                    c = C.c_uint32(0)
-                    capi.check(dev.lib.rt_device_listed_rays(dev.handle, C.byref(c)), "rt_device_listed_rays")
+                    c, during, whole = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+                    capi.check(dev.lib.rt_device_listed_rays_detail(dev.handle, C.byref(c), C.byref(during), C.byref(whole)),
+                               "rt_device_listed_rays_detail")
                     listed += c.value
+                    run.in_parts += c.value if c.value <= 512 else 0
+                    run.whole_after_parts += whole.value
             got.append((p.result_image().copy(), p.emitted.download(np.float32, 4 * w * h).copy(), p.rays.download(np.float32, 8 * w * h).copy()))
             p.close()
         if oracle:
@@ -162,7 +166,9 @@ def main():
     w, h, calls = 256, 144, 4
     only = {int(x) for x in os.environ["FUZZ_ONLY"].split(",")} if os.environ.get("FUZZ_ONLY") else None
     bad, listed = run(Device(0), cases, seed, w, h, calls, against_oracle=len(sys.argv) > 3 and sys.argv[3] == "oracle", only=only)
-    print("%d cases, %d with differences, %d rays listed in all (of %d traced)" % (cases, bad, listed, cases * calls * w * h))
+    print("%d cases, %d with differences, %d rays listed in all (of %d traced); %d of them on lists of up to 512 rays (walked in parts "
+          "where GPURT_LISTED_SPLIT or a recent call says so), %d walked whole after a part ran out of room"
+          % (cases, bad, listed, cases * calls * w * h, run.in_parts, run.whole_after_parts))
     sys.exit(1 if bad else 0)
 
 

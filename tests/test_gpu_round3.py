@@ -187,6 +187,58 @@ def test_c1_settings_defaults_on_the_substitute_scene(device, oracle):
     assert want["output"][..., :3].max() > 0.0
 
 
+def test_a_short_list_of_rays_is_walked_in_parts_with_the_same_result(device, oracle):
+    """The rays the default kernel lists for the walk in the reference's order are few on a real scene (a few dozen per
+    call on the reference's room, assets/testscene2.obj) and their walk is long; a short list is dealt out in parts, one
+    subtree of the reference's hierarchy per lane, and put together by k_listed_merge. Always in parts, never in parts and
+    by expectation (the default: in parts once a call has listed rays) - every buffer is the oracle's; and a scene of
+    coincident copies, whose parts run out of room for their candidates, takes the way back to the whole walk."""
+    from gpuraytracer_amd import capi
+    from gpuraytracer_amd.pipeline import Pipeline
+    from tests.test_gpu_round2 import _golden_scene, _same, _seeds
+    lib = device.lib
+    sc = _golden_scene("testscene2")
+    w, h, cycles, depth = 640, 360, 2, 3
+    want = _oracle(oracle, sc, w, h, cycles, depth)
+    try:
+        for mode in (1, 2, 0):
+            capi.check(lib.rt_device_set_listed_split(device.handle, mode), "rt_device_set_listed_split")
+            _same(_render(device, oracle, sc, w, h, cycles, depth, KERNEL_SPATIAL), want, "testscene2, listed rays in parts: mode %d" % mode)
+        # the list really is short and not empty there (else the three modes would have nothing to tell apart)
+        capi.check(lib.rt_device_set_listed_split(device.handle, 1), "rt_device_set_listed_split")
+        cam = sc["camera"]
+        iv, ip = oracle.camera_matrices(cam["position"], cam["focus"], cam["up"], cam["fov"], w / h, cam["near_z"], cam["far_z"])
+        ri, ti = _seeds(oracle, cycles, depth)
+        gp = Pipeline(device, sc, w, h, iv, ip, depth=depth, raygen_seeds=lambda: next(ri), trace_seeds=lambda: next(ti))
+        listed = 0
+        for _ in range(cycles * depth):
+            gp.render(1)
+            total, during, whole = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+            capi.check(lib.rt_device_listed_rays_detail(device.handle, C.byref(total), C.byref(during), C.byref(whole)), "rt_device_listed_rays_detail")
+            assert total.value <= 512 and whole.value <= total.value
+            listed += total.value
+        gp.close()
+        assert listed > 0, "testscene2 lists rays at this size"
+        # twelve coincident copies of a soup in front of a wall: equal distances, flat boxes - parts with more candidates than
+        # they have room for
+        rng = np.random.RandomState(5)
+        soup = _soup(40, rng, half=4.0, edge=3.0)
+        wall = np.array([[[-30, -30, 9], [30, -30, 9], [30, 30, 9]], [[-30, -30, 9], [30, 30, 9], [-30, 30, 9]]], dtype=np.float32)
+        crowd = _scene_of(np.concatenate([np.tile(soup, (12, 1, 1)), wall]), "coincident-copies")
+        want2 = _oracle(oracle, crowd, 160, 90, 2, 3)
+        overflowed = 0
+        for mode in (1, 2):
+            capi.check(lib.rt_device_set_listed_split(device.handle, mode), "rt_device_set_listed_split")
+            _same(_render(device, oracle, crowd, 160, 90, 2, 3, KERNEL_SPATIAL), want2, "coincident copies, mode %d" % mode)
+            if mode == 1:
+                whole = C.c_uint32(0)
+                lib.rt_device_listed_rays_detail(device.handle, C.byref(C.c_uint32(0)), C.byref(C.c_uint32(0)), C.byref(whole))
+                overflowed = whole.value
+        print("coincident copies: rays of the last call walked whole after their parts ran out of room:", overflowed)
+    finally:
+        lib.rt_device_set_listed_split(device.handle, 0)
+
+
 def test_headless_cli_refuses_more_ranks_than_the_machine_has_gpus(device):
     import os
     import subprocess
