@@ -21,7 +21,8 @@
 //    re-test at the leaves), k_traverse (one level per step on exact sibling pairs; its counting variant reproduces
 //    the reference's box-test count), k_trace (one thread per ray; also the brute-force path without a hierarchy).
 //  * The default, k_traverse_spatial, finds the same closest hits on a second hierarchy of the library's own and hands
-//    the rays for which the reference's order could decide to k_traverse_quad (see the description at the kernel).
+//    the rays for which the reference's order could decide to k_traverse_quad (see the description at the kernel); a
+//    short list of such rays is walked in parts, one subtree per lane (k_traverse_quad<true>, k_listed_merge).
 //
 // Arithmetic conventions are those of rt_math.h; the slab test multiplies by one IEEE reciprocal of
 // each direction component per ray instead of dividing per box.
