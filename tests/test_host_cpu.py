@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
     # what a maintainer binds carries no test-only switch or counter
     main = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", open(headers[0]).read()))
     assert not main & {"rt_device_set_walk_margins", "rt_device_set_trace_stats", "rt_device_set_walk_stats", "rt_device_listed_rays",
-                       "rt_device_set_traverse_timing", "rt_device_traverse_timing"}
+                       "rt_device_set_traverse_timing", "rt_device_traverse_timing", "rt_device_listed_rays_detail",
+                       "rt_device_set_listed_split"}
     for name in declared:
         assert hasattr(lib, name), "libgpurt.so does not export %s" % name
 
