@@ -77,7 +77,8 @@ class ImageRows(C.Structure):
 class TraceTuning(C.Structure):
     """rt_trace_tuning: knobs of the persistent traversal kernels (no setting changes a result)."""
     _fields_ = [(n, C.c_uint32) for n in ("leaf_threshold", "refill_threshold", "blocks_per_cu", "sort_rays", "deal_shift",
-                                          "cost_bits", "cost_depth", "cost_stride", "cost_chord", "key_passes", "stuck_threshold")]
+                                          "cost_bits", "cost_depth", "cost_stride", "cost_chord", "key_passes", "stuck_threshold",
+                                          "retire_us")]
 
 
 class GenerateFinalImageInfo(C.Structure):

@@ -77,6 +77,7 @@ int rt_device_create(int gpu_index, rt_device** out) {
         t.cost_chord = env("GPURT_COST_CHORD", 2u);
         t.key_passes = env("GPURT_KEY_PASSES", 0u);
         t.stuck_threshold = env("GPURT_STUCK_THRESHOLD", 0u);
+        t.retire_us = env("GPURT_RETIRE_US", 40u);
         d->tuning = rt_clamp_tuning(t);
         const uint32_t in_parts = env("GPURT_LISTED_SPLIT", 0u);      // rt_device_set_listed_split
         d->listed_split = in_parts <= 2u ? (int)in_parts : 0;

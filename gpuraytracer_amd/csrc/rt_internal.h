@@ -103,6 +103,7 @@ static inline rt_trace_tuning rt_clamp_tuning(rt_trace_tuning t) {
     if (t.cost_chord > 2u) t.cost_chord = 2u;
     if (t.key_passes > 3u) t.key_passes = 3u;
     if (t.stuck_threshold > 64u) t.stuck_threshold = 64u;
+    if (t.retire_us > 1000u) t.retire_us = 1000u;
     return t;
 }
 

@@ -56,6 +56,7 @@ struct TraceParams {
     uint32_t trunk_children;   // node index (reference layout) of the first of the trunk's two children, for hierarchy lv
     uint32_t stuck_threshold;  // k_traverse_spatial: lanes whose walk is over with leaves still waiting that start a triangle round
     uint32_t walk_hist;        // counting variant of k_traverse_spatial: the counter buffer also has room for steps by depth
+    uint32_t retire_ticks;     // k_traverse_spatial: workgroups of class c take no more rays once the queues will be empty within c * retire_ticks (of the 100 MHz clock; 0: off)
     rt_levels lv;
 };
 
@@ -1214,6 +1215,17 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
     uint32_t q = blockIdx.x & 7u, queues_tried = 0u;       // wave-uniform
     uint32_t n_steps = 0u, n_empty = 0u, n_leaves = 0u;    // COUNT: this wave's steps, steps that hit nothing, leaves tested
     uint32_t n_turns = 0u, n_rounds = 0u;                  // COUNT: turns of the walking loop and triangle rounds of this wave
+    // The end of a launch. When the queues run dry every wave still holds a hundred rays, and works them off with fewer and
+    // fewer lanes - while the three other waves of its SIMD do the same, each turn of each of them taking its full share of
+    // the SIMD's issue slots: a quarter of the rays of a two-million-ray launch, and half a millisecond on the benchmark's
+    // scene, whatever the size of the launch. So the workgroups do not all stay to the end: those of class c (a quarter of
+    // the grid each, in launch order - each CU gets one workgroup of every class, i.e. every SIMD one wave) take no more
+    // rays once the queues will be empty within c * retire_ticks at the pace so far (what is left in the wave's queue, over
+    // what has been taken from it, times the time since the wave started), run out while the others still work at full
+    // width, and leave; the last rays are walked by one wave per SIMD, whose turns then take a fraction of the time.
+    // Class 0 never stops: every ray is taken.
+    const uint32_t retire_class = p.retire_ticks ? blockIdx.x / max(gridDim.x >> 2, 1u) : 0u;
+    const unsigned long long retire_t0 = retire_class ? wall_clock64() : 0ull;
     // COUNT: this wave's steps by depth of the entered node (two levels per entry: slot 1 is depth 0)
     uint32_t* s_hist = s_dyn + kFifo * 512u + 4u * kStockFields * 64u + (tid >> 6) * 16u;
     if (COUNT) {
@@ -1238,6 +1250,13 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                     q = (q + 1u) & 7u;
                     queues_tried++;
                     continue;
+                }
+                // (the eight queues empty at the same pace: what is left in this one is an eighth of what is left)
+                if (retire_class != 0u) {
+                    // (the eight queues empty at the same pace)
+                    const uint32_t taken = base + 64u - q_begin, left = q_end - min(q_end, base + 64u);
+                    const float to_go = (float)(wall_clock64() - retire_t0) * ((float)left / (float)taken);
+                    if (to_go < (float)(retire_class * p.retire_ticks)) queues_tried = 8u;      // these 64 are its last
                 }
                 const uint32_t mine = base + lane;
                 bool keep = false;
@@ -1700,6 +1719,7 @@ int trace_common(rt_device* dev, const rt_trace_rays_info* info, int use_bvh, co
     p.refill_threshold = tune.refill_threshold ? tune.refill_threshold : (spatial_kernel ? 8u : 16u);
     p.deal_shift = tune.deal_shift;
     p.stuck_threshold = tune.stuck_threshold ? tune.stuck_threshold : 4u;
+    p.retire_ticks = 100u * tune.retire_us;           // of the 100 MHz clock the kernel reads
     p.beyond = dev->walk_entry_margin;
     const uint32_t deal_block = 1u << p.deal_shift;
     p.queue_chunk = ((((nr + deal_block - 1u) / deal_block) + 7u) / 8u) * deal_block;      // whole blocks, dealt to the eight queues in turn

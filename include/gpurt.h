@@ -137,6 +137,10 @@ typedef struct {
     uint32_t key_passes;        /* GPURT_KEY_PASSES: 8-bit sorting passes over the ray keys, 1 .. 3; 0 = default */
     uint32_t stuck_threshold;   /* GPURT_STUCK_THRESHOLD: SPATIAL only - lanes whose walk is over but whose leaves still wait that
                                    start a triangle round before leaf_threshold is reached; 0 = 4 */
+    uint32_t retire_us;         /* GPURT_RETIRE_US: SPATIAL only - the end of a launch: the persistent workgroups stop taking rays in
+                                   four turns, a quarter of them each time the ray queues are another retire_us microseconds (at
+                                   the pace so far) from empty, so that the last rays are walked by one wave per SIMD instead of
+                                   by four that share its issue slots; 0 = all stay to the end, default 40, at most 1000 */
 } rt_trace_tuning;
 int rt_device_get_trace_tuning(rt_device* dev, rt_trace_tuning* out);
 int rt_device_set_trace_tuning(rt_device* dev, const rt_trace_tuning* tuning);   /* out-of-range values are clamped */

@@ -364,9 +364,10 @@ def test_every_tuning_knob_keeps_the_oracle_image(device, oracle):
     base = capi.TraceTuning()
     capi.check(device.lib.rt_device_get_trace_tuning(device.handle, C.byref(base)), "rt_device_get_trace_tuning")
     knobs = dict(leaf_threshold=5, refill_threshold=40, blocks_per_cu=2, sort_rays=0, deal_shift=9, cost_bits=9, cost_depth=7,
-                 cost_stride=3, cost_chord=0, key_passes=1, stuck_threshold=1)
+                 cost_stride=3, cost_chord=0, key_passes=1, stuck_threshold=1, retire_us=7)
     cases = [{k: v} for k, v in knobs.items()] + [dict(knobs), dict(cost_chord=1, key_passes=3), dict(leaf_threshold=64, refill_threshold=1),
                                                             dict(sort_rays=1), dict(sort_rays=2), dict(stuck_threshold=64), dict(stuck_threshold=9, leaf_threshold=50),
+                                                            dict(retire_us=0), dict(retire_us=1000), dict(retire_us=200, blocks_per_cu=3),
                                                             # (the probe on the library's own hierarchy reads its sibling-pair records, for which all
                                                             # of its node levels are made on demand: builds store only the levels the walk needs)
                                                             dict(sort_rays=1, cost_depth=7, cost_chord=0), dict(sort_rays=1, cost_depth=3, cost_stride=1, cost_chord=0)]
@@ -379,11 +380,12 @@ def test_every_tuning_knob_keeps_the_oracle_image(device, oracle):
             g = _gpu_render(device, oracle, sc, w, h, cycles, depth, kernel=kernel, tuning=t, keep=ALL)
             _same(g, want, "tuning %s, kernel %d" % (case, kernel))
     # out-of-range values are clamped, not refused
-    t = capi.TraceTuning(*([1000] * 11))
+    t = capi.TraceTuning(*([5000] * 12))
     capi.check(device.lib.rt_device_set_trace_tuning(device.handle, C.byref(t)), "rt_device_set_trace_tuning")
     got = capi.TraceTuning()
     device.lib.rt_device_get_trace_tuning(device.handle, C.byref(got))
-    assert (got.leaf_threshold, got.blocks_per_cu, got.deal_shift, got.cost_bits, got.key_passes, got.sort_rays, got.stuck_threshold) == (64, 8, 20, 12, 3, 1, 64)
+    assert (got.leaf_threshold, got.blocks_per_cu, got.deal_shift, got.cost_bits, got.key_passes, got.sort_rays, got.stuck_threshold,
+            got.retire_us) == (64, 8, 20, 12, 3, 1, 64, 1000)
     device.lib.rt_device_set_trace_tuning(device.handle, C.byref(base))
 
 
