@@ -1283,14 +1283,48 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
                 }
                 if (outlier_records) {
                     // the outliers first, by every lane that has a ray (the records' addresses are the same for all lanes):
-                    // a scene's walls and floor bound the reach of most rays before the walk begins
+                    // a scene's walls and floor bound the reach of most rays before the walk begins.
+                    // A ray's hit is confirmed against its leaf in the reference's order (walk_hits_consider) once, behind the
+                    // last record, by all lanes together - most rays hit one outlier at most (the wall they end on); a lane that
+                    // finds a second hit confirms the other one there and then. The order of confirming does not enter the result.
                     const float c_lim = (c_tmin > 0.0f) ? c_tmin : __uint_as_float(1u);
-                    for (uint32_t j = 0u; j < outlier_records; j++) {
-                        const float4* t = outlier_leaves + RT_LEAF_STRIDE * j;
-                        const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
-                        const float2 places = *reinterpret_cast<const float2*>(t + 5);
-                        if (valid)
-                            walk_hits_leaf(c_hits, c_org, c_dir, c_inv, c_tmin, c_tmax, c_lim, kBeyond, l0, l1, l2, l3, l4, places, ref_leaf_bytes);
+                    Hit held;
+                    held.t = held.u = held.v = held.w = 0.0f;
+                    uint32_t held_ci = 0u, held_rank = 0xffffffffu;
+                    for (uint32_t j = 0u; j <= outlier_records; j++) {
+                        const bool last = j == outlier_records;
+                        uint32_t todo = held_rank != 0xffffffffu ? 4u : 0u;
+                        Hit h0, h1;
+                        h0.t = h0.u = h0.v = h0.w = 0.0f; h1 = h0;
+                        uint32_t ci0 = 0u, ci1 = 0u, place0 = 0u, place1 = 0u;
+                        if (!last) {
+                            const float4* t = outlier_leaves + RT_LEAF_STRIDE * j;
+                            const float4 l0 = t[0], l1 = t[1], l2 = t[2], l3 = t[3], l4 = t[4];
+                            const float2 places = *reinterpret_cast<const float2*>(t + 5);
+                            if (valid) {
+                                ci0 = __float_as_uint(l4.z); ci1 = __float_as_uint(l4.w);
+                                place0 = __float_as_uint(places.x); place1 = __float_as_uint(places.y);
+                                intersect_leaf(c_org, c_dir, l0, l1, l2, l3, l4, h0, h1);
+                                if ((c_tmin <= h0.t) && (c_tmax > h0.t) && (h0.t <= c_hits.reach)) todo |= 1u;
+                                if ((ci1 != 0xffffffffu) && (c_tmin <= h1.t) && (c_tmax > h1.t) && (h1.t <= c_hits.reach)) todo |= 2u;
+                            }
+                        }
+#pragma unroll 1
+                        while ((todo & (todo - 1u)) != 0u || (last && todo != 0u)) {
+                            const bool k1 = (todo & 3u) == 2u, kh = (todo & 3u) == 0u;      // the record's second triangle, the held hit
+                            Hit hk;
+                            hk.t = kh ? held.t : (k1 ? h1.t : h0.t); hk.u = kh ? held.u : (k1 ? h1.u : h0.u);
+                            hk.v = kh ? held.v : (k1 ? h1.v : h0.v); hk.w = kh ? held.w : (k1 ? h1.w : h0.w);
+                            walk_hits_consider(c_hits, hk, kh ? held_ci : (k1 ? ci1 : ci0), kh ? held_rank : (k1 ? place1 : place0), c_org, c_inv,
+                                               c_lim, c_tmax, kBeyond, ref_leaf_bytes);
+                            todo &= todo - 1u;
+                        }
+                        if (todo & 3u) {                      // this record's one hit that is left waits
+                            const bool k1 = (todo & 1u) == 0u;
+                            held.t = k1 ? h1.t : h0.t; held.u = k1 ? h1.u : h0.u; held.v = k1 ? h1.v : h0.v; held.w = k1 ? h1.w : h0.w;
+                            held_ci = k1 ? ci1 : ci0;
+                            held_rank = k1 ? place1 : place0;
+                        }
                     }
                 }
                 if (valid) {
