@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 
 #include <rccl/rccl.h>
 
@@ -37,10 +38,25 @@ RcclApi g_rccl;
 std::once_flag g_rccl_once;
 
 void load_rccl() {
+    // First the RCCL that lies beside the HIP runtime this library is bound to. A process can hold two ROCm stacks - the
+    // system's and the one a Python package brings along, under the same sonames -, and a plain dlopen("librccl.so.1")
+    // returns whichever copy is loaded already: one bound to the other stack's HIP runtime finds no device.
+    Dl_info hip;
+    if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &hip) && hip.dli_fname) {
+        std::string dir(hip.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash + 1u);
+            for (const char* n : {"librccl.so.1", "librccl.so"}) {
+                g_rccl.handle = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL);
+                if (g_rccl.handle) break;
+            }
+        }
+    }
     const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     for (const char* n : names) {
-        g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (g_rccl.handle) break;
+        g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     }
     if (!g_rccl.handle) return;
     void* h = g_rccl.handle;

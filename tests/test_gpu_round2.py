@@ -556,6 +556,9 @@ def test_gather_rows_over_rccl_with_one_rank(device, oracle):
     sends its rows to itself (an RCCL send/receive pair) and the root puts them in image order. Also through
     RaytracerPipeline::GatherOutput of the C++ host."""
     from gpuraytracer_amd import capi, host_py, scenes
+    # (PyTorch brings a ROCm stack of its own along, RCCL included; the library must bind the RCCL that belongs to the HIP
+    # runtime it runs on whether PyTorch was imported before the library was loaded, after it, or not at all)
+    import gpuraytracer_amd.distributed  # noqa: F401 - imports torch
     lib = device.lib
     uid = (C.c_ubyte * capi.RT_COMM_ID_BYTES)()
     capi.check(lib.rt_comm_unique_id(uid), "rt_comm_unique_id")
