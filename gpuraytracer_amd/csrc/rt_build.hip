@@ -1584,9 +1584,10 @@ int rt_accel_destroy(rt_accel* a) {
 
 int rt_accel_set_second_hierarchy(rt_accel* a, int enable, uint32_t cell_bits) {
     if (!a) return RT_ERR_INVALID_ARGUMENT;
-    a->want_spatial = enable != 0;
     a->cell_bits_cap = cell_bits > RT_CELL_BITS_MAX ? RT_CELL_BITS_MAX : cell_bits;
-    return RT_OK;
+    // (an accel beyond RT_SPATIAL_SLOTS_MAX leaf slots was created without room for it: asking for it says so)
+    a->want_spatial = enable != 0 && a->sp_tris != nullptr;
+    return enable != 0 && !a->sp_tris ? RT_ERR_LIMIT_EXCEEDED : RT_OK;
 }
 
 int rt_accel_outliers(rt_accel* a, uint32_t* found, uint32_t* listed) {

@@ -165,7 +165,7 @@ const char* rt_error_string(int code) {
         case RT_ERR_TOO_FEW_PRIMITIVES: return "fewer than 3 primitives";
         case RT_ERR_BUFFER_TOO_SMALL: return "buffer too small";
         case RT_ERR_OUT_OF_MEMORY: return "out of memory";
-        case RT_ERR_LIMIT_EXCEEDED: return "size beyond the fixed limit of an entry point that allocates nothing";
+        case RT_ERR_LIMIT_EXCEEDED: return "size beyond a fixed limit (of an entry point that allocates nothing, or of the second hierarchy)";
         default: break;
     }
     if (code == RT_ERR_RCCL_UNAVAILABLE) return "librccl.so.1 could not be loaded";

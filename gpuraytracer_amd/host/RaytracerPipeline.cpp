@@ -313,13 +313,27 @@ namespace RT::GraphicsAPI
 	bool BuildBVH::CreateAccel()
 	{
 		if (rt_accel_create(m_rtDevice, m_iNumPrimitives, &m_rtAccel) != RT_OK) return false;
-		return rt_accel_set_second_hierarchy(m_rtAccel, m_bSecondHierarchy ? 1 : 0, 0xffffffffu) == RT_OK;
+		return ApplySecondHierarchy();
+	}
+
+	//a scene too large for the library's own hierarchy is still rendered (by the walk in the reference's order), but not
+	//without a word: that walk is some twenty times slower
+	bool BuildBVH::ApplySecondHierarchy()
+	{
+		const int iResult = rt_accel_set_second_hierarchy(m_rtAccel, m_bSecondHierarchy ? 1 : 0, 0xffffffffu);
+		if (iResult == RT_ERR_LIMIT_EXCEEDED)
+		{
+			std::fprintf(stderr, "BuildBVH: %u triangles are more than the library's own hierarchy holds; tracing by the walk in the "
+				"reference's order (RT_TRACE_KERNEL_QUAD), which is much slower\n", m_iNumPrimitives);
+			return true;
+		}
+		return iResult == RT_OK;
 	}
 
 	void BuildBVH::SetSecondHierarchy(bool bEnable)
 	{
 		m_bSecondHierarchy = bEnable;
-		if (m_rtAccel) rt_accel_set_second_hierarchy(m_rtAccel, bEnable ? 1 : 0, 0xffffffffu);
+		if (m_rtAccel) ApplySecondHierarchy();
 	}
 
 	bool BuildBVH::BuildFusedMoved(RaytracerMesh* rtMesh, rt_buffer* rtBounds, rt_buffer* rtMortonCodes)

@@ -109,6 +109,7 @@ namespace RT::GraphicsAPI
 		bool m_bSecondHierarchy;
 
 		bool CreateAccel();
+		bool ApplySecondHierarchy();
 
 	public:
 		BuildBVH();

@@ -30,7 +30,7 @@ extern "C" {
 #define RT_ERR_TOO_FEW_PRIMITIVES 2 /* fewer than 3 triangles: the reference's level loop never ends */
 #define RT_ERR_BUFFER_TOO_SMALL 3
 #define RT_ERR_OUT_OF_MEMORY 4
-#define RT_ERR_LIMIT_EXCEEDED 5     /* beyond the fixed limit of an entry point that allocates nothing */
+#define RT_ERR_LIMIT_EXCEEDED 5     /* beyond a fixed limit: of an entry point that allocates nothing, of the second hierarchy */
 #define RT_ERR_RCCL_UNAVAILABLE 6   /* librccl.so.1 could not be loaded (multi-GPU entry points only) */
 #define RT_ERR_HIP_BASE 0x1000      /* 0x1000 + hipError_t */
 #define RT_ERR_RCCL_BASE 0x2000     /* 0x2000 + ncclResult_t */
@@ -225,7 +225,9 @@ int rt_accel_destroy(rt_accel* accel);
 /* Whether builds of this accel also make the library's own hierarchy (what RT_TRACE_KERNEL_SPATIAL walks; on by
  * default where it fits), and the finest Morton cells its leaf slots may be aligned to: cell_bits in 0, 3, 6, .. 21
  * (0 = leaves by rank only; anything above 21 means 21, the default). Takes effect at the next build; an accel whose last build did not make it is traced by
- * RT_TRACE_KERNEL_QUAD. */
+ * RT_TRACE_KERNEL_QUAD. Enabling it on an accel that is too large for it (more than 2^26 leaf slots, see rt_accel_create)
+ * returns RT_ERR_LIMIT_EXCEEDED and leaves it off: such an accel works, traced by the much slower RT_TRACE_KERNEL_QUAD, and
+ * a caller that asks learns of it here rather than from the frame time. */
 int rt_accel_set_second_hierarchy(rt_accel* accel, int enable, uint32_t cell_bits);
 /* Gathers Indices -> Vertices -> positions into the accel's packed triangle array
  * (3 x float4 per triangle, original order). Call after the mesh changes. */
