@@ -218,8 +218,8 @@ int rt_generate_final_image(rt_device* dev, const rt_generate_final_image_info* 
  *      src/RaytracerPipeline.cpp:276-383, 475-562, with identical results) ---- */
 uint32_t rt_bvh_node_count(uint32_t num_primitives);     /* nodes the hierarchy uses; 0 if < 3 primitives */
 /* Allocates every workspace once: packed triangles, sort keys, the private copies of the reference's hierarchy and,
- * up to 2^26 leaf slots (about 67 M triangles), the library's own hierarchy for RT_TRACE_KERNEL_SPATIAL - about
- * 1 KB per triangle in all. */
+ * up to 2^26 leaf slots (134 M triangles; up to 67 M the hierarchy has twice as many slots as leaves), the library's own
+ * hierarchy for RT_TRACE_KERNEL_SPATIAL - about 1 KB per triangle in all. */
 int rt_accel_create(rt_device* dev, uint32_t max_primitives, rt_accel** out);
 int rt_accel_destroy(rt_accel* accel);
 /* Whether builds of this accel also make the library's own hierarchy (what RT_TRACE_KERNEL_SPATIAL walks; on by

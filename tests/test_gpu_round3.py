@@ -240,13 +240,13 @@ def test_a_short_list_of_rays_is_walked_in_parts_with_the_same_result(device, or
 
 
 def test_an_accel_too_large_for_the_second_hierarchy_says_so_when_asked(device):
-    """Beyond 2^26 leaf slots (about 67 M triangles) an accel is created without the library's own hierarchy and traced by the
+    """Beyond 2^26 leaf slots (134 M triangles) an accel is created without the library's own hierarchy and traced by the
     walk in the reference's order: rt_accel_set_second_hierarchy(enable) on it returns RT_ERR_LIMIT_EXCEEDED (switching it off
     is fine), on an accel that has room RT_OK. Creation only: nothing is built."""
     from gpuraytracer_amd import capi
     lib = device.lib
     big, small = C.c_void_p(), C.c_void_p()
-    capi.check(lib.rt_accel_create(device.handle, 70_000_000, C.byref(big)), "rt_accel_create")
+    capi.check(lib.rt_accel_create(device.handle, 140_000_000, C.byref(big)), "rt_accel_create")
     try:
         assert lib.rt_accel_set_second_hierarchy(big, 1, 21) == capi.RT_ERR_LIMIT_EXCEEDED
         assert lib.rt_accel_set_second_hierarchy(big, 0, 21) == capi.RT_OK
