@@ -1405,6 +1405,11 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
         // 2. walk until a triangle round is due, a lane has finished its ray, or nobody can walk
         unsigned long long waiting_mask, walking_mask;
         uint32_t stuck = 0u;
+        // (leaf_threshold is meant of 64 lanes with a ray each: a wave with fewer rays - the end of a launch, a small scene,
+        // lanes waiting for the next refill - starts its rounds at the same share of them, so that a hit still shortens its
+        // ray's walk in time)
+        const uint32_t with_ray = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(w < kIdle));
+        const uint32_t round_at = max(1u, (with_ray * p.leaf_threshold + 63u) >> 6);
         for (;;) {
             bool empty_step = false;                       // COUNT: this lane's step found none of the four boxes hit
             if (COUNT) { n_turns += 1u; n_steps += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(w <= kFifo - 1u)); }
@@ -1468,12 +1473,12 @@ __global__ __launch_bounds__(256) void k_traverse_spatial(TraceParams p, const f
             // (lanes whose walk is over wait for a triangle round with nothing else to do: a few of them start one
             // before the waiting leaves alone would)
             stuck = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(w > kOver && w < kIdle));
-            if (!walking_mask || (uint32_t)__popcll(waiting_mask) >= p.leaf_threshold || stuck >= p.stuck_threshold) break;
+            if (!walking_mask || (uint32_t)__popcll(waiting_mask) >= round_at || stuck >= p.stuck_threshold) break;
             if ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(w >= kOver && w != kDry)) >= p.refill_threshold) break;
         }
 
         // 3. triangle round once enough lanes have a leaf waiting (or nobody can walk any more)
-        if (waiting_mask && ((uint32_t)__popcll(waiting_mask) >= p.leaf_threshold || !walking_mask || stuck >= p.stuck_threshold)) {
+        if (waiting_mask && ((uint32_t)__popcll(waiting_mask) >= round_at || !walking_mask || stuck >= p.stuck_threshold)) {
             if (COUNT) n_rounds += 1u;
             bool tested = false;                           // COUNT: this lane tests a leaf in this round
             if ((w & 15u) != 0u) {

@@ -123,7 +123,8 @@ int rt_device_set_slab_division(rt_device* dev, int enable);
  * device starts from the defaults, or from the environment variables named beside the fields, read once by
  * rt_device_create. 0 = the library's default where stated. */
 typedef struct {
-    uint32_t leaf_threshold;    /* GPURT_LEAF_THRESHOLD: lanes with a leaf waiting that start a triangle round; 0 = 32 (SPATIAL) / 16 */
+    uint32_t leaf_threshold;    /* GPURT_LEAF_THRESHOLD: lanes with a leaf waiting that start a triangle round; 0 = 32 (SPATIAL, where it is
+                                   meant of 64 lanes and scaled to the lanes of the wave that have a ray) / 16 */
     uint32_t refill_threshold;  /* GPURT_REFILL_THRESHOLD: free lanes that start a refill; 0 = 8 (SPATIAL) / 16 */
     uint32_t blocks_per_cu;     /* GPURT_BLOCKS_PER_CU: persistent workgroups per compute unit; default 4 */
     uint32_t sort_rays;         /* GPURT_SORT_RAYS: 1 = order the rays of a launch by estimated walk length, 0 = as they come,
